@@ -1,0 +1,55 @@
+"""Compiles the HIP sources of this package for gfx950 into multigrid_prj_amd/lib/libmg_hip.so.
+
+Plain `hipcc -shared` (no torch extension): the boundary is a C-ABI shared library.
+hipcc cross-compiles without a GPU, so this also runs in the build container.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmg_hip.so")
+
+SOURCES = ["mg_kernels.hip", "mg_jacobi_fast.hip", "mg_solver.cpp", "mg_capi.cpp"]
+HEADERS = ["mg_geom.h", "mg_kernels.h", "mg_solver.h"]
+# -ffp-contract=off: products and sums round separately, like the reference built for
+# baseline x86-64 -- required for bit parity with the oracle.
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _inputs():
+    files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    files += [os.path.join(ROOT, "include", f) for f in ("mg_hip.h", "mg_desc.h")]
+    return [f for f in files if os.path.exists(f)]
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(f) > t for f in _inputs())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, *FLAGS, "-I" + os.path.join(ROOT, "include"), *srcs, "-o", LIB_PATH + ".tmp"]
+    if os.environ.get("MG_WITH_RCCL", "1") == "1" and os.path.exists("/opt/rocm/lib/librccl.so"):
+        cmd += ["-DMG_WITH_RCCL=1", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

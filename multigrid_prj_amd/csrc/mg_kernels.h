@@ -1,0 +1,59 @@
+// mg_kernels.h -- launchers of the hand-written gfx950 kernels (mg_kernels.hip,
+// mg_jacobi_fast.hip). All launchers only enqueue on `s`; none synchronises.
+#ifndef MG_KERNELS_H
+#define MG_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include "mg_geom.h"
+
+namespace mg {
+
+// number of per-block partial sums a reduction launch over `g` may produce
+int reduce_partials_capacity(const Geom &g);
+
+template <typename T>
+void launch_jacobi(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u,
+                   const T *rhs, T *out);
+
+// one colour half-sweep of red-black Gauss-Seidel, in place
+template <typename T>
+void launch_rbgs_colour(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u,
+                        const T *rhs);
+
+// lexicographic Gauss-Seidel, one persistent workgroup, diagonal wavefronts
+template <typename T>
+void launch_gs_lex(hipStream_t s, const Geom &g, const Coef<T> &c, int sweeps, T *u,
+                   const T *rhs);
+
+// r = rhs - A u (r may be null), sum r^2 -> *d_sumsq (device double), two-pass
+// deterministic reduction through d_partials
+template <typename T>
+void launch_residual(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs,
+                     T *r, double *d_partials, double *d_sumsq);
+
+template <typename T>
+void launch_sumsq(hipStream_t s, const Geom &g, const T *v, double *d_partials, double *d_sumsq);
+
+// coarse(K,J,I) = fine(2K,2J,2I)   (gc = coarse geometry, gf = fine geometry)
+template <typename T>
+void launch_inject(hipStream_t s, const Geom &gf, const Geom &gc, const T *fine, T *coarse);
+template <typename T>
+void launch_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, const T *fine, T *coarse);
+
+// fine = P coarse (add == false, overwrite) or fine += P coarse
+template <typename T>
+void launch_prolong(hipStream_t s, const Geom &gc, const Geom &gf, const T *coarse, T *fine,
+                    bool add);
+
+// u += e; e = 0
+template <typename T>
+void launch_correct(hipStream_t s, const Geom &g, T *u, T *e);
+
+// Solver::Solve in one persistent workgroup; result vector ends in x
+template <typename T>
+void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, int smoother,
+                         T *x, T *tmp, const T *rhs, int maxit, double tol, int fixed,
+                         CoarseOut *d_out);
+
+}  // namespace mg
+#endif

@@ -1,0 +1,602 @@
+// mg_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the
+// geometric-multigrid hot path.  Generic versions: correct for every level size,
+// dimension and precision; the finest-grid fast paths live in mg_jacobi_fast.hip.
+//
+// Arithmetic contract (checked bit for bit against oracle/ by tests/):
+//  * compiled with -ffp-contract=off: every product and sum rounds separately, in
+//    the reference's order  (k-1),(j-1),(i-1),[c],(i+1),(j+1),(k+1)
+//    (reference src/domain.cpp:36-38, include/solvers.hpp:36-46,70-80,265-273);
+//  * true IEEE division by the diagonal, like `/ m_A.coeffRef(i,i)`;
+//  * norms: per-thread double accumulation -> wave64 shuffle tree -> per-block
+//    partial -> second kernel that adds the partials in a fixed order, so a norm
+//    is reproducible run to run (no float atomics), but its summation order
+//    differs from the reference's serial loop (tolerance 1e-12 relative in tests).
+//
+// Nothing here is a dense contraction: MFMA is deliberately unused; every kernel
+// is priced against the HBM roofline.
+#include "mg_kernels.h"
+
+namespace mg {
+
+namespace {
+
+constexpr int BX = 64;  // one wave64 spans 64 consecutive x
+constexpr int BY = 4;   // 4 waves per workgroup, stacked in y
+
+__device__ __forceinline__ long long lidx(const Geom &g, int z, int y, int x)
+{
+    return (long long)z * g.plane + (long long)y * g.pitch + x;
+}
+
+__device__ __forceinline__ bool on_boundary(const Geom &g, int z, int y, int x)
+{
+    // reference src/domain.cpp:20-23, extended to the slab-decomposed z axis
+    bool b = (x == 0) | (y == 0) | (x == g.nx - 1) | (y == g.ny - 1);
+    if (g.dim == 3) {
+        int gz = g.gz0 + z;
+        b |= (gz == 0) | (gz == g.gnz - 1);
+    }
+    return b;
+}
+
+template <typename T, int DIM>
+__device__ __forceinline__ T offdiag_sum(const T *u, long long i, int pitch,
+                                         long long plane, const Coef<T> &c)
+{
+    T sum = 0;
+    if (DIM == 3) sum += c.cz * u[i - plane];
+    sum += c.cy * u[i - pitch];
+    sum += c.cx * u[i - 1];
+    sum += c.cx * u[i + 1];
+    sum += c.cy * u[i + pitch];
+    if (DIM == 3) sum += c.cz * u[i + plane];
+    return sum;
+}
+
+template <typename T, int DIM>
+__device__ __forceinline__ T full_sum(const T *u, long long i, int pitch,
+                                      long long plane, const Coef<T> &c)
+{
+    // Residual: diagonal included, in row order (solvers.hpp:269-271)
+    T sum = 0;
+    if (DIM == 3) sum += c.cz * u[i - plane];
+    sum += c.cy * u[i - pitch];
+    sum += c.cx * u[i - 1];
+    sum += c.cd * u[i];
+    sum += c.cx * u[i + 1];
+    sum += c.cy * u[i + pitch];
+    if (DIM == 3) sum += c.cz * u[i + plane];
+    return sum;
+}
+
+template <typename T, int DIM, bool DAMPED>
+__device__ __forceinline__ T point_update(const Geom &g, const Coef<T> &c, T omega,
+                                          const T *u, const T *rhs, int z, int y, int x)
+{
+    long long i = lidx(g, z, y, x);
+    T b = rhs[i];
+    if (on_boundary(g, z, y, x)) return b;  // (b - 0) / 1
+    T sum = offdiag_sum<T, DIM>(u, i, g.pitch, g.plane, c);
+    T jac = (b - sum) / c.cd;
+    if (DAMPED) {
+        T uc = u[i];
+        return uc + omega * (jac - uc);
+    }
+    return jac;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// sum over the workgroup; every thread gets the same value. sh: >= 18 doubles.
+__device__ __forceinline__ double block_sum_bcast(double v, double *sh)
+{
+    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    const int nthreads = blockDim.x * blockDim.y * blockDim.z;
+    const int nw = (nthreads + 63) >> 6;
+    v = wave_sum(v);
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0;
+        for (int w = 0; w < nw; w++) s += sh[w];
+        sh[17] = s;
+    }
+    __syncthreads();
+    double r = sh[17];
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------- Jacobi (generic)
+template <typename T, int DIM, bool DAMPED>
+__global__ __launch_bounds__(BX *BY) void k_jacobi(Geom g, Coef<T> c, T omega,
+                                                   const T *__restrict__ u,
+                                                   const T *__restrict__ rhs, T *__restrict__ out)
+{
+    int x = blockIdx.x * BX + threadIdx.x;
+    int y = blockIdx.y * BY + threadIdx.y;
+    int z = blockIdx.z;
+    if (x >= g.nx || y >= g.ny) return;
+    out[lidx(g, z, y, x)] = point_update<T, DIM, DAMPED>(g, c, omega, u, rhs, z, y, x);
+}
+
+// ---------------------------------------------------------------- red-black GS
+template <typename T, int DIM>
+__global__ __launch_bounds__(BX *BY) void k_rbgs(Geom g, Coef<T> c, int colour, T *u,
+                                                 const T *__restrict__ rhs)
+{
+    // each lane owns one point of the requested colour: x = 2*lane_x + offset
+    int y = blockIdx.y * BY + threadIdx.y;
+    int z = blockIdx.z;
+    if (y >= g.ny) return;
+    int par = (y + g.gz0 + z + colour) & 1;  // x parity that has (x+y+gz)&1 == colour
+    int x = 2 * (blockIdx.x * BX + threadIdx.x) + par;
+    if (x >= g.nx) return;
+    u[lidx(g, z, y, x)] = point_update<T, DIM, false>(g, c, (T)1, u, rhs, z, y, x);
+}
+
+// ---------------------------------------------------------------- residual + norm
+template <typename T, int DIM, bool SAVE, bool NORM>
+__global__ __launch_bounds__(BX *BY) void k_residual(Geom g, Coef<T> c,
+                                                     const T *__restrict__ u,
+                                                     const T *__restrict__ rhs, T *__restrict__ r,
+                                                     double *__restrict__ partials)
+{
+    __shared__ double sh[18];
+    int x = blockIdx.x * BX + threadIdx.x;
+    int y = blockIdx.y * BY + threadIdx.y;
+    int z = blockIdx.z;
+    double sq = 0.;
+    if (x < g.nx && y < g.ny) {
+        long long i = lidx(g, z, y, x);
+        T sum;
+        if (on_boundary(g, z, y, x)) sum = (T)1 * u[i];
+        else sum = full_sum<T, DIM>(u, i, g.pitch, g.plane, c);
+        T res = rhs[i] - sum;
+        if (SAVE) r[i] = res;
+        sq = (double)res * (double)res;
+    }
+    if (NORM) {
+        double tot = block_sum_bcast(sq, sh);
+        if (threadIdx.x == 0 && threadIdx.y == 0)
+            partials[blockIdx.x + gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z)] = tot;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BX *BY) void k_sumsq(Geom g, const T *__restrict__ v,
+                                                  double *__restrict__ partials)
+{
+    __shared__ double sh[18];
+    int x = blockIdx.x * BX + threadIdx.x;
+    int y = blockIdx.y * BY + threadIdx.y;
+    int z = blockIdx.z;
+    double sq = 0.;
+    if (x < g.nx && y < g.ny) {
+        double t = (double)v[lidx(g, z, y, x)];
+        sq = t * t;
+    }
+    double tot = block_sum_bcast(sq, sh);
+    if (threadIdx.x == 0 && threadIdx.y == 0)
+        partials[blockIdx.x + gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z)] = tot;
+}
+
+// fixed-order final reduction: thread t adds partials t, t+1024, ... then the tree
+__global__ __launch_bounds__(1024) void k_reduce_final(const double *__restrict__ partials,
+                                                       long long n, double *__restrict__ out)
+{
+    __shared__ double sh[18];
+    double s = 0.;
+    for (long long i = threadIdx.x; i < n; i += 1024) s += partials[i];
+    double tot = block_sum_bcast(s, sh);
+    if (threadIdx.x == 0) *out = tot;
+}
+
+// ---------------------------------------------------------------- transfers
+template <typename T>
+__global__ __launch_bounds__(BX *BY) void k_inject(Geom gf, Geom gc, const T *__restrict__ fine,
+                                                   T *__restrict__ coarse)
+{
+    int x = blockIdx.x * BX + threadIdx.x;
+    int y = blockIdx.y * BY + threadIdx.y;
+    int z = blockIdx.z;
+    if (x >= gc.nx || y >= gc.ny) return;
+    int fz = (gc.dim == 3) ? 2 * (gc.gz0 + z) - gf.gz0 : 0;
+    coarse[lidx(gc, z, y, x)] = fine[lidx(gf, fz, 2 * y, 2 * x)];
+}
+
+template <typename T, int DIM>
+__global__ __launch_bounds__(BX *BY) void k_restrict_fw(Geom gf, Geom gc,
+                                                        const T *__restrict__ fine,
+                                                        T *__restrict__ coarse)
+{
+    int x = blockIdx.x * BX + threadIdx.x;
+    int y = blockIdx.y * BY + threadIdx.y;
+    int z = blockIdx.z;
+    if (x >= gc.nx || y >= gc.ny) return;
+    int fz = (DIM == 3) ? 2 * (gc.gz0 + z) - gf.gz0 : 0;
+    long long fi = lidx(gf, fz, 2 * y, 2 * x);
+    T out;
+    if (on_boundary(gc, z, y, x)) {
+        out = fine[fi];
+    } else {
+        const T q = (T)0.25, hlf = (T)0.5;
+        T zacc[3];
+#pragma unroll
+        for (int dz = 0; dz < (DIM == 3 ? 3 : 1); dz++) {
+            long long oz = (DIM == 3) ? (long long)(dz - 1) * gf.plane : 0;
+            T yacc[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                const T *p = fine + fi + oz + (long long)(dy - 1) * gf.pitch;
+                yacc[dy] = q * p[-1] + hlf * p[0] + q * p[1];
+            }
+            zacc[dz] = q * yacc[0] + hlf * yacc[1] + q * yacc[2];
+        }
+        out = (DIM == 3) ? q * zacc[0] + hlf * zacc[1] + q * zacc[2] : zacc[0];
+    }
+    coarse[lidx(gc, z, y, x)] = out;
+}
+
+// Interpolated value at fine node (zf,yf,xf), built in the reference's phase order
+// (src/multigrid.cpp:3-27; slow axis first, fast axis last) so that every fine node
+// gets bit for bit what the in-place sequential phases produce.
+template <typename T, int DIM>
+__device__ __forceinline__ T interp_z(const Geom &gc, const T *__restrict__ c, int gzf, int yc,
+                                      int xc)
+{
+    if (DIM == 2) return c[lidx(gc, 0, yc, xc)];
+    if ((gzf & 1) == 0) return c[lidx(gc, (gzf >> 1) - gc.gz0, yc, xc)];
+    int k0 = ((gzf - 1) >> 1) - gc.gz0;
+    return (T)0.5 * (c[lidx(gc, k0, yc, xc)] + c[lidx(gc, k0 + 1, yc, xc)]);
+}
+template <typename T, int DIM>
+__device__ __forceinline__ T interp_y(const Geom &gc, const T *__restrict__ c, int gzf, int yf,
+                                      int xc)
+{
+    if ((yf & 1) == 0) return interp_z<T, DIM>(gc, c, gzf, yf >> 1, xc);
+    return (T)0.5 * (interp_z<T, DIM>(gc, c, gzf, (yf - 1) >> 1, xc) +
+                     interp_z<T, DIM>(gc, c, gzf, (yf + 1) >> 1, xc));
+}
+template <typename T, int DIM, bool ADD>
+__global__ __launch_bounds__(BX *BY) void k_prolong(Geom gc, Geom gf,
+                                                    const T *__restrict__ coarse,
+                                                    T *__restrict__ fine)
+{
+    int x = blockIdx.x * BX + threadIdx.x;
+    int y = blockIdx.y * BY + threadIdx.y;
+    int z = blockIdx.z;
+    if (x >= gf.nx || y >= gf.ny) return;
+    int gzf = gf.gz0 + z;
+    T v;
+    if ((x & 1) == 0) v = interp_y<T, DIM>(gc, coarse, gzf, y, x >> 1);
+    else v = (T)0.5 * (interp_y<T, DIM>(gc, coarse, gzf, y, (x - 1) >> 1) +
+                       interp_y<T, DIM>(gc, coarse, gzf, y, (x + 1) >> 1));
+    long long i = lidx(gf, z, y, x);
+    if (ADD) fine[i] += v; else fine[i] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BX *BY) void k_correct(Geom g, T *__restrict__ u, T *__restrict__ e)
+{
+    int x = blockIdx.x * BX + threadIdx.x;
+    int y = blockIdx.y * BY + threadIdx.y;
+    int z = blockIdx.z;
+    if (x >= g.nx || y >= g.ny) return;
+    long long i = lidx(g, z, y, x);
+    u[i] += e[i];
+    e[i] = 0;
+}
+
+// ---------------------------------------------------------------- single-workgroup sweeps
+// Device-side sweeps executed by ONE workgroup of 1024 threads (coarsest grid,
+// and the bit-faithful lexicographic GS on any level). Each ends with a barrier.
+constexpr int SWG = 1024;
+
+template <typename T, int DIM, bool DAMPED>
+__device__ void wg_jacobi(const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs,
+                          T *out)
+{
+    const int npl = g.nx * g.ny;
+    const long long total = (long long)npl * g.nz;
+    for (long long q = threadIdx.x; q < total; q += SWG) {
+        int z = (int)(q / npl);
+        int rem = (int)(q - (long long)z * npl);
+        int y = rem / g.nx, x = rem - y * g.nx;
+        out[lidx(g, z, y, x)] = point_update<T, DIM, DAMPED>(g, c, omega, u, rhs, z, y, x);
+    }
+    __syncthreads();
+}
+
+template <typename T, int DIM>
+__device__ void wg_rbgs(const Geom &g, const Coef<T> &c, T *u, const T *rhs)
+{
+    const int npl = g.nx * g.ny;
+    const long long total = (long long)npl * g.nz;
+    for (int colour = 0; colour < 2; colour++) {
+        for (long long q = threadIdx.x; q < total; q += SWG) {
+            int z = (int)(q / npl);
+            int rem = (int)(q - (long long)z * npl);
+            int y = rem / g.nx, x = rem - y * g.nx;
+            if (((x + y + g.gz0 + z) & 1) != colour) continue;
+            u[lidx(g, z, y, x)] = point_update<T, DIM, false>(g, c, (T)1, u, rhs, z, y, x);
+        }
+        __syncthreads();
+    }
+}
+
+// Lexicographic Gauss-Seidel (solvers.hpp:33-48) as anti-diagonal wavefronts:
+// inside a plane, point (y,x) needs the NEW (y-1,x),(y,x-1) and the OLD
+// (y+1,x),(y,x+1); all points with x+y == d are independent once diagonal d-1 is
+// done. Planes go in order (new z-1, old z+1). Same inputs per point as the
+// serial loop => bit-identical result.
+template <typename T, int DIM>
+__device__ void wg_gs_lex(const Geom &g, const Coef<T> &c, T *u, const T *rhs)
+{
+    for (int z = 0; z < g.nz; z++) {
+        for (int d = 0; d <= g.nx + g.ny - 2; d++) {
+            int ylo = max(0, d - (g.nx - 1));
+            int yhi = min(g.ny - 1, d);
+            for (int y = ylo + (int)threadIdx.x; y <= yhi; y += SWG) {
+                int x = d - y;
+                u[lidx(g, z, y, x)] = point_update<T, DIM, false>(g, c, (T)1, u, rhs, z, y, x);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T, int DIM>
+__device__ double wg_residual_sumsq(const Geom &g, const Coef<T> &c, const T *u, const T *rhs,
+                                    double *sh)
+{
+    const int npl = g.nx * g.ny;
+    const long long total = (long long)npl * g.nz;
+    double sq = 0.;
+    for (long long q = threadIdx.x; q < total; q += SWG) {
+        int z = (int)(q / npl);
+        int rem = (int)(q - (long long)z * npl);
+        int y = rem / g.nx, x = rem - y * g.nx;
+        long long i = lidx(g, z, y, x);
+        T sum;
+        if (on_boundary(g, z, y, x)) sum = (T)1 * u[i];
+        else sum = full_sum<T, DIM>(u, i, g.pitch, g.plane, c);
+        T res = rhs[i] - sum;
+        sq += (double)res * (double)res;
+    }
+    return block_sum_bcast(sq, sh);
+}
+
+template <typename T>
+__device__ double wg_sumsq(const Geom &g, const T *v, double *sh)
+{
+    const int npl = g.nx * g.ny;
+    const long long total = (long long)npl * g.nz;
+    double sq = 0.;
+    for (long long q = threadIdx.x; q < total; q += SWG) {
+        int z = (int)(q / npl);
+        int rem = (int)(q - (long long)z * npl);
+        int y = rem / g.nx, x = rem - y * g.nx;
+        double t = (double)v[lidx(g, z, y, x)];
+        sq += t * t;
+    }
+    return block_sum_bcast(sq, sh);
+}
+
+template <typename T, int DIM>
+__global__ __launch_bounds__(SWG) void k_gs_lex(Geom g, Coef<T> c, int sweeps, T *u, const T *rhs)
+{
+    for (int s = 0; s < sweeps; s++) wg_gs_lex<T, DIM>(g, c, u, rhs);
+}
+
+// Solver::Solve (solvers.hpp:324-342) with (maxit, tol, step = 1) -- the whole
+// iterate-to-tolerance loop in one launch: no host round trip per iteration.
+// Exit condition reached by every wave: the loop variable `counter` is bounded
+// by maxit and all threads see the same broadcast norm.
+template <typename T, int DIM>
+__global__ __launch_bounds__(SWG) void k_coarse_solve(Geom g, Coef<T> c, T omega, int smoother,
+                                                      T *x, T *tmp, const T *rhs, int maxit,
+                                                      double tol, int fixed, CoarseOut *out)
+{
+    __shared__ double sh[18];
+    T *cur = x, *oth = tmp;
+    const bool damped = (omega != (T)1);
+    auto sweep = [&]() {
+        if (smoother == 1) {
+            if (damped) wg_jacobi<T, DIM, true>(g, c, omega, cur, rhs, oth);
+            else wg_jacobi<T, DIM, false>(g, c, omega, cur, rhs, oth);
+            T *t = cur; cur = oth; oth = t;
+        } else if (smoother == 2) {
+            wg_rbgs<T, DIM>(g, c, cur, rhs);
+        } else {
+            wg_gs_lex<T, DIM>(g, c, cur, rhs);
+        }
+    };
+    double nb = wg_sumsq<T>(g, rhs, sh);  // refresh_normalization_constant, :244-254
+    int iters = 0, flag = 0;
+    double nr;
+    if (fixed) {
+        for (int s = 0; s < maxit; s++) sweep();
+        iters = maxit;
+        nr = wg_residual_sumsq<T, DIM>(g, c, cur, rhs, sh);
+    } else {
+        int counter = maxit;
+        nr = wg_residual_sumsq<T, DIM>(g, c, cur, rhs, sh);
+        while (sqrt(nr / nb) > tol) {  // NaN (zero rhs) compares false, like the reference
+            if (counter > 0) {
+                sweep();
+                counter -= 1;
+                iters++;
+                nr = wg_residual_sumsq<T, DIM>(g, c, cur, rhs, sh);
+            } else {
+                flag = 1;
+                break;
+            }
+        }
+    }
+    if (cur != x) {  // odd number of Jacobi sweeps: move the result back into x
+        const int npl = g.nx * g.ny;
+        const long long total = (long long)npl * g.nz;
+        for (long long q = threadIdx.x; q < total; q += SWG) {
+            int z = (int)(q / npl);
+            int rem = (int)(q - (long long)z * npl);
+            int y = rem / g.nx, xx = rem - y * g.nx;
+            long long i = lidx(g, z, y, xx);
+            x[i] = cur[i];
+        }
+    }
+    if (threadIdx.x == 0) {
+        out->iters = iters;
+        out->flag = flag;
+        out->relres = sqrt(nr / nb);
+        out->sumsq_rhs = nb;
+        out->sumsq_r = nr;
+    }
+}
+
+inline dim3 grid_for(int nx, int ny, int nz)
+{
+    return dim3((nx + BX - 1) / BX, (ny + BY - 1) / BY, nz);
+}
+
+}  // namespace
+
+int reduce_partials_capacity(const Geom &g)
+{
+    dim3 gr = grid_for(g.nx, g.ny, g.nz);
+    return (int)(gr.x * gr.y * gr.z);
+}
+
+template <typename T>
+void launch_jacobi(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u,
+                   const T *rhs, T *out)
+{
+    dim3 gr = grid_for(g.nx, g.ny, g.nz), bl(BX, BY, 1);
+    const bool damped = (omega != (T)1);
+    if (g.dim == 3) {
+        if (damped) hipLaunchKernelGGL((k_jacobi<T, 3, true>), gr, bl, 0, s, g, c, omega, u, rhs, out);
+        else hipLaunchKernelGGL((k_jacobi<T, 3, false>), gr, bl, 0, s, g, c, omega, u, rhs, out);
+    } else {
+        if (damped) hipLaunchKernelGGL((k_jacobi<T, 2, true>), gr, bl, 0, s, g, c, omega, u, rhs, out);
+        else hipLaunchKernelGGL((k_jacobi<T, 2, false>), gr, bl, 0, s, g, c, omega, u, rhs, out);
+    }
+}
+
+template <typename T>
+void launch_rbgs_colour(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u,
+                        const T *rhs)
+{
+    dim3 gr = grid_for((g.nx + 1) / 2, g.ny, g.nz), bl(BX, BY, 1);
+    if (g.dim == 3) hipLaunchKernelGGL((k_rbgs<T, 3>), gr, bl, 0, s, g, c, colour, u, rhs);
+    else hipLaunchKernelGGL((k_rbgs<T, 2>), gr, bl, 0, s, g, c, colour, u, rhs);
+}
+
+template <typename T>
+void launch_gs_lex(hipStream_t s, const Geom &g, const Coef<T> &c, int sweeps, T *u, const T *rhs)
+{
+    if (g.dim == 3) hipLaunchKernelGGL((k_gs_lex<T, 3>), dim3(1), dim3(SWG), 0, s, g, c, sweeps, u, rhs);
+    else hipLaunchKernelGGL((k_gs_lex<T, 2>), dim3(1), dim3(SWG), 0, s, g, c, sweeps, u, rhs);
+}
+
+template <typename T>
+void launch_residual(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs,
+                     T *r, double *d_partials, double *d_sumsq)
+{
+    // d_sumsq == nullptr: residual vector only (V-cycle restriction input), no norm
+    dim3 gr = grid_for(g.nx, g.ny, g.nz), bl(BX, BY, 1);
+    long long nb = (long long)gr.x * gr.y * gr.z;
+#define MG_RES(DIM, SAVE, NORM) \
+    hipLaunchKernelGGL((k_residual<T, DIM, SAVE, NORM>), gr, bl, 0, s, g, c, u, rhs, r, d_partials)
+    if (g.dim == 3) {
+        if (d_sumsq) { if (r) MG_RES(3, true, true); else MG_RES(3, false, true); }
+        else MG_RES(3, true, false);
+    } else {
+        if (d_sumsq) { if (r) MG_RES(2, true, true); else MG_RES(2, false, true); }
+        else MG_RES(2, true, false);
+    }
+#undef MG_RES
+    if (d_sumsq) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, d_partials, nb, d_sumsq);
+}
+
+template <typename T>
+void launch_sumsq(hipStream_t s, const Geom &g, const T *v, double *d_partials, double *d_sumsq)
+{
+    dim3 gr = grid_for(g.nx, g.ny, g.nz), bl(BX, BY, 1);
+    long long nb = (long long)gr.x * gr.y * gr.z;
+    hipLaunchKernelGGL((k_sumsq<T>), gr, bl, 0, s, g, v, d_partials);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, d_partials, nb, d_sumsq);
+}
+
+template <typename T>
+void launch_inject(hipStream_t s, const Geom &gf, const Geom &gc, const T *fine, T *coarse)
+{
+    dim3 gr = grid_for(gc.nx, gc.ny, gc.nz), bl(BX, BY, 1);
+    hipLaunchKernelGGL((k_inject<T>), gr, bl, 0, s, gf, gc, fine, coarse);
+}
+
+template <typename T>
+void launch_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, const T *fine, T *coarse)
+{
+    dim3 gr = grid_for(gc.nx, gc.ny, gc.nz), bl(BX, BY, 1);
+    if (gc.dim == 3) hipLaunchKernelGGL((k_restrict_fw<T, 3>), gr, bl, 0, s, gf, gc, fine, coarse);
+    else hipLaunchKernelGGL((k_restrict_fw<T, 2>), gr, bl, 0, s, gf, gc, fine, coarse);
+}
+
+template <typename T>
+void launch_prolong(hipStream_t s, const Geom &gc, const Geom &gf, const T *coarse, T *fine,
+                    bool add)
+{
+    dim3 gr = grid_for(gf.nx, gf.ny, gf.nz), bl(BX, BY, 1);
+    if (gf.dim == 3) {
+        if (add) hipLaunchKernelGGL((k_prolong<T, 3, true>), gr, bl, 0, s, gc, gf, coarse, fine);
+        else hipLaunchKernelGGL((k_prolong<T, 3, false>), gr, bl, 0, s, gc, gf, coarse, fine);
+    } else {
+        if (add) hipLaunchKernelGGL((k_prolong<T, 2, true>), gr, bl, 0, s, gc, gf, coarse, fine);
+        else hipLaunchKernelGGL((k_prolong<T, 2, false>), gr, bl, 0, s, gc, gf, coarse, fine);
+    }
+}
+
+template <typename T>
+void launch_correct(hipStream_t s, const Geom &g, T *u, T *e)
+{
+    dim3 gr = grid_for(g.nx, g.ny, g.nz), bl(BX, BY, 1);
+    hipLaunchKernelGGL((k_correct<T>), gr, bl, 0, s, g, u, e);
+}
+
+template <typename T>
+void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, int smoother,
+                         T *x, T *tmp, const T *rhs, int maxit, double tol, int fixed,
+                         CoarseOut *d_out)
+{
+    if (g.dim == 3)
+        hipLaunchKernelGGL((k_coarse_solve<T, 3>), dim3(1), dim3(SWG), 0, s, g, c, omega, smoother, x,
+                           tmp, rhs, maxit, tol, fixed, d_out);
+    else
+        hipLaunchKernelGGL((k_coarse_solve<T, 2>), dim3(1), dim3(SWG), 0, s, g, c, omega, smoother, x,
+                           tmp, rhs, maxit, tol, fixed, d_out);
+}
+
+#define MG_INSTANTIATE(T)                                                                          \
+    template void launch_jacobi<T>(hipStream_t, const Geom &, const Coef<T> &, T, const T *,       \
+                                   const T *, T *);                                                \
+    template void launch_rbgs_colour<T>(hipStream_t, const Geom &, const Coef<T> &, int, T *,      \
+                                        const T *);                                                \
+    template void launch_gs_lex<T>(hipStream_t, const Geom &, const Coef<T> &, int, T *, const T *); \
+    template void launch_residual<T>(hipStream_t, const Geom &, const Coef<T> &, const T *,        \
+                                     const T *, T *, double *, double *);                          \
+    template void launch_sumsq<T>(hipStream_t, const Geom &, const T *, double *, double *);       \
+    template void launch_inject<T>(hipStream_t, const Geom &, const Geom &, const T *, T *);       \
+    template void launch_restrict_fw<T>(hipStream_t, const Geom &, const Geom &, const T *, T *);  \
+    template void launch_prolong<T>(hipStream_t, const Geom &, const Geom &, const T *, T *, bool); \
+    template void launch_correct<T>(hipStream_t, const Geom &, T *, T *);                          \
+    template void launch_coarse_solve<T>(hipStream_t, const Geom &, const Coef<T> &, T, int, T *,  \
+                                         T *, const T *, int, double, int, CoarseOut *);
+MG_INSTANTIATE(double)
+MG_INSTANTIATE(float)
+
+}  // namespace mg

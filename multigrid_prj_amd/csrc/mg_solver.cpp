@@ -1,0 +1,532 @@
+// mg_solver.cpp -- grid hierarchy in HBM + stream-ordered cycle drivers.
+// Reference call structure being replaced: SawtoothMGIteration
+// (include/multigrid.hpp:108-145) and the outer loop of src/main.cpp:72-116.
+#include "mg_solver.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "mg_kernels.h"
+
+namespace mg {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+const std::string &last_error() { return g_last_error; }
+
+#define MG_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            set_last_error(std::string(#call) + ": " + hipGetErrorString(e_));               \
+            return MG_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+int validate_desc(const mg_desc *d, std::string *why)
+{
+    auto fail = [&](const char *m) { if (why) *why = m; return (int)MG_ERR_INVALID_DESC; };
+    if (!d) return fail("null descriptor");
+    if (d->dim != 2 && d->dim != 3) return fail("dim must be 2 or 3");
+    if (d->levels < 1 || d->levels > 16) return fail("levels must be in 1..16");
+    if (d->n < 3) return fail("n must be >= 3");
+    long step = 1L << (d->levels - 1);
+    // The reference accepts any n (e.g. its defaults n=200, levels=2) and then reads
+    // out of range on the coarse grid; we refuse instead.
+    if ((d->n - 1) % step != 0) return fail("n-1 must be a multiple of 2^(levels-1)");
+    if ((d->n - 1) / step + 1 < 3) return fail("coarsest grid would have fewer than 3 nodes per side");
+    if (d->dtype != MG_F64 && d->dtype != MG_F32) return fail("dtype must be MG_F64 or MG_F32");
+    if (d->smoother < MG_SMOOTH_GS_LEX || d->smoother > MG_SMOOTH_RBGS) return fail("unknown smoother");
+    if (d->cycle != MG_CYCLE_SAWTOOTH && d->cycle != MG_CYCLE_V) return fail("unknown cycle kind");
+    if (d->restriction != MG_RESTRICT_INJECT && d->restriction != MG_RESTRICT_FULLW) return fail("unknown restriction");
+    if (d->coarse_mode != MG_COARSE_TOL && d->coarse_mode != MG_COARSE_FIXED) return fail("unknown coarse mode");
+    if (!(d->length > 0) || !(d->alpha > 0)) return fail("length and alpha must be positive");
+    if (d->coarse_maxit < 0 || d->nu_pre < 0 || d->nu_post < 0 || d->outer_pre_gs < 0)
+        return fail("negative sweep count");
+    for (int a = 0; a < 3; a++)
+        if (!(d->aniso[a] > 0)) return fail("aniso multipliers must be positive");
+    return MG_OK;
+}
+
+int level_n(const mg_desc &d, int level)
+{
+    int n = d.n;
+    for (int l = 0; l < level; l++) n = (n + 1) / 2;  // reference src/domain.cpp:9-12
+    return n;
+}
+
+void level_coefficients(const mg_desc &d, int level, double out[4])
+{
+    // reference: m_h = length/(size-1) (domain.cpp:5); h() = m_h*step (domain.hpp:90);
+    // k = h*h (linear_system.hpp:17); -alpha/k and 4*alpha/k (linear_system.hpp:27-28,37-38)
+    double m_h = d.length / (double)(d.n - 1);
+    double step = (double)(1L << level);
+    double h = m_h * step;
+    double k = h * h;
+    out[0] = -(d.alpha * d.aniso[0]) / k;
+    out[1] = -(d.alpha * d.aniso[1]) / k;
+    out[2] = -(d.alpha * d.aniso[2]) / k;
+    double s = (d.dim == 3) ? (d.aniso[0] + d.aniso[1] + d.aniso[2]) : (d.aniso[0] + d.aniso[1]);
+    out[3] = ((2.0 * s) * d.alpha) / k;
+}
+
+int plan_slab(const mg_desc &d, int nranks, int rank, int level, SlabPlan *out, std::string *why)
+{
+    auto fail = [&](const char *m) { if (why) *why = m; return (int)MG_ERR_BAD_ARG; };
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("bad rank / nranks");
+    if (level < 0 || level >= d.levels) return fail("bad level");
+    if (nranks > 1 && d.dim != 3) return fail("domain decomposition needs dim == 3");
+    // Distributed levels 0..Ld-1: every rank keeps >= 2 coarse cells and the level has
+    // >= 33 nodes per side; coarser levels are agglomerated on rank 0.
+    int Ld = d.levels;
+    if (nranks > 1) {
+        Ld = 0;
+        for (int l = 0; l < d.levels; l++) {
+            int cells = (d.n - 1) >> l;
+            if (cells >= 2 * nranks && cells + 1 >= 33) Ld = l + 1; else break;
+        }
+        if (Ld == 0) return fail("grid too small for this many ranks");
+    }
+    out->first_gathered_level = Ld;
+    int n_l = level_n(d, level);
+    if (d.dim == 2) { out->z0 = 0; out->nz = 1; return MG_OK; }
+    if (level >= Ld) {  // gathered: rank 0 owns everything
+        out->z0 = 0;
+        out->nz = (rank == 0) ? n_l : 0;
+        return MG_OK;
+    }
+    // split the cells of the coarsest distributed level; finer levels inherit it
+    int cellsC = (d.n - 1) >> (Ld - 1);
+    int shift = (Ld - 1) - level;
+    long s0 = ((long)cellsC * rank) / nranks, s1 = ((long)cellsC * (rank + 1)) / nranks;
+    out->z0 = (int)(s0 << shift);
+    out->nz = (int)((s1 - s0) << shift) + ((rank == nranks - 1) ? 1 : 0);
+    return MG_OK;
+}
+
+Solver::Solver(const mg_desc &d, int device) : d_(d), device_(device) {}
+
+Solver::~Solver()
+{
+    if (device_ >= 0) (void)hipSetDevice(device_);
+    for (auto &L : lv_)
+        for (auto &b : L.base)
+            if (b) (void)hipFree(b);
+    if (d_partials_) (void)hipFree(d_partials_);
+    if (d_scal_) (void)hipFree(d_scal_);
+    if (d_coarse_) (void)hipFree(d_coarse_);
+    if (h_scal_) (void)hipHostFree(h_scal_);
+    if (h_coarse_) (void)hipHostFree(h_coarse_);
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+int Solver::init()
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_last_error("no HIP device: libmg_hip has no CPU fallback");
+        return MG_ERR_NO_DEVICE;
+    }
+    if (device_ < 0) MG_HIP(hipGetDevice(&device_));
+    if (device_ >= ndev) { set_last_error("device index out of range"); return MG_ERR_BAD_ARG; }
+    MG_HIP(hipSetDevice(device_));
+    MG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    MG_HIP(hipEventCreate(&ev0_));
+    MG_HIP(hipEventCreate(&ev1_));
+
+    const int epl = (int)(128 / esize());  // elements per 128-byte line
+    lv_.resize(d_.levels);
+    int max_partials = 1;
+    for (int l = 0; l < d_.levels; l++) {
+        Level &L = lv_[l];
+        int n = level_n(d_, l);
+        L.g.dim = d_.dim;
+        L.g.nx = n; L.g.ny = n; L.g.nz = (d_.dim == 3) ? n : 1;
+        L.g.pitch = ((n + epl - 1) / epl) * epl;
+        L.g.plane = (long long)L.g.ny * L.g.pitch;
+        L.g.gz0 = 0; L.g.gnz = L.g.nz;
+        L.alloc_elems = (size_t)(L.g.nz + 2) * (size_t)L.g.plane;
+        level_coefficients(d_, l, L.coef);
+        for (int a = 0; a < NUM_ARR; a++) {
+            if (a == MG_ARR_RES && l > 0) continue;
+            size_t nbytes = L.alloc_elems * esize();
+            MG_HIP(hipMalloc(&L.base[a], nbytes));
+            MG_HIP(hipMemsetAsync(L.base[a], 0, nbytes, stream_));
+            bytes_ += nbytes;
+        }
+        int cap = reduce_partials_capacity(L.g);
+        if (cap > max_partials) max_partials = cap;
+    }
+    MG_HIP(hipMalloc((void **)&d_partials_, sizeof(double) * (size_t)max_partials));
+    MG_HIP(hipMalloc((void **)&d_scal_, sizeof(double) * 8));
+    MG_HIP(hipMalloc((void **)&d_coarse_, sizeof(CoarseOut)));
+    MG_HIP(hipMemsetAsync(d_scal_, 0, sizeof(double) * 8, stream_));
+    MG_HIP(hipMemsetAsync(d_coarse_, 0, sizeof(CoarseOut), stream_));
+    MG_HIP(hipHostMalloc((void **)&h_scal_, sizeof(double) * 8));
+    MG_HIP(hipHostMalloc((void **)&h_coarse_, sizeof(CoarseOut)));
+    bytes_ += sizeof(double) * ((size_t)max_partials + 8) + sizeof(CoarseOut);
+    MG_HIP(hipStreamSynchronize(stream_));
+    return MG_OK;
+}
+
+bool Solver::check_arr(int which, int level, const char *fn) const
+{
+    if (level < 0 || level >= d_.levels || which < 0 || which >= NUM_ARR || !lv_[level].base[which]) {
+        set_last_error(std::string(fn) + ": no such array/level");
+        return false;
+    }
+    return true;
+}
+
+template <typename T>
+T *Solver::ptr(int which, int level) const
+{
+    const Level &L = lv_[level];
+    return reinterpret_cast<T *>(L.base[which]) + L.g.plane;  // skip the lower ghost plane
+}
+
+int Solver::set_array(int which, int level, const void *host)
+{
+    if (!host || !check_arr(which, level, "mg_set_array")) return MG_ERR_BAD_ARG;
+    MG_HIP(hipSetDevice(device_));
+    const Level &L = lv_[level];
+    char *dst = reinterpret_cast<char *>(L.base[which]) + (size_t)L.g.plane * esize();
+    MG_HIP(hipMemcpy2DAsync(dst, (size_t)L.g.pitch * esize(), host, (size_t)L.g.nx * esize(),
+                            (size_t)L.g.nx * esize(), (size_t)L.g.ny * L.g.nz,
+                            hipMemcpyHostToDevice, stream_));
+    MG_HIP(hipStreamSynchronize(stream_));
+    return MG_OK;
+}
+
+int Solver::get_array(int which, int level, void *host)
+{
+    if (!host || !check_arr(which, level, "mg_get_array")) return MG_ERR_BAD_ARG;
+    MG_HIP(hipSetDevice(device_));
+    const Level &L = lv_[level];
+    const char *src = reinterpret_cast<const char *>(L.base[which]) + (size_t)L.g.plane * esize();
+    MG_HIP(hipMemcpy2DAsync(host, (size_t)L.g.nx * esize(), src, (size_t)L.g.pitch * esize(),
+                            (size_t)L.g.nx * esize(), (size_t)L.g.ny * L.g.nz,
+                            hipMemcpyDeviceToHost, stream_));
+    MG_HIP(hipStreamSynchronize(stream_));
+    return MG_OK;
+}
+
+int Solver::zero_array(int which, int level)
+{
+    if (!check_arr(which, level, "mg_zero_array")) return MG_ERR_BAD_ARG;
+    MG_HIP(hipMemsetAsync(lv_[level].base[which], 0, lv_[level].alloc_elems * esize(), stream_));
+    return MG_OK;
+}
+
+template <typename T>
+static Coef<T> coef_of(const Level &L)
+{
+    return Coef<T>{(T)L.coef[0], (T)L.coef[1], (T)L.coef[2], (T)L.coef[3]};
+}
+
+template <typename T>
+int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar)
+{
+    Level &L = lv_[level];
+    Coef<T> c = coef_of<T>(L);
+    switch (smoother) {
+    case MG_SMOOTH_JACOBI:
+        for (int s = 0; s < sweeps; s++) {
+            launch_jacobi<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level),
+                             ptr<T>(MG_ARR_TMP, level));
+            // the reference swaps the std::vector buffers (solvers.hpp:82); so do we
+            std::swap(L.base[ax], L.base[MG_ARR_TMP]);
+        }
+        break;
+    case MG_SMOOTH_RBGS:
+        for (int s = 0; s < sweeps; s++) {
+            launch_rbgs_colour<T>(stream_, L.g, c, 0, ptr<T>(ax, level), ptr<T>(ar, level));
+            launch_rbgs_colour<T>(stream_, L.g, c, 1, ptr<T>(ax, level), ptr<T>(ar, level));
+        }
+        break;
+    default:
+        if (sweeps > 0) launch_gs_lex<T>(stream_, L.g, c, sweeps, ptr<T>(ax, level), ptr<T>(ar, level));
+        break;
+    }
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+}
+
+int Solver::smooth(int level, int smoother, int sweeps, int arr_x, int arr_rhs)
+{
+    if (!check_arr(arr_x, level, "mg_smooth") || !check_arr(arr_rhs, level, "mg_smooth")) return MG_ERR_BAD_ARG;
+    if (arr_x == MG_ARR_TMP || arr_rhs == MG_ARR_TMP || arr_x == arr_rhs || sweeps < 0 ||
+        smoother < MG_SMOOTH_GS_LEX || smoother > MG_SMOOTH_RBGS) {
+        set_last_error("mg_smooth: bad array / smoother / sweeps");
+        return MG_ERR_BAD_ARG;
+    }
+    MG_HIP(hipSetDevice(device_));
+    return d_.dtype == MG_F64 ? smooth_t<double>(level, smoother, sweeps, arr_x, arr_rhs)
+                              : smooth_t<float>(level, smoother, sweeps, arr_x, arr_rhs);
+}
+
+template <typename T>
+int Solver::residual_t(int level, int ax, int ar, int arr_r, bool want_norm)
+{
+    Level &L = lv_[level];
+    launch_residual<T>(stream_, L.g, coef_of<T>(L), ptr<T>(ax, level), ptr<T>(ar, level),
+                       arr_r >= 0 ? ptr<T>(arr_r, level) : (T *)nullptr, d_partials_,
+                       want_norm ? d_scal_ : (double *)nullptr);
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+}
+
+int Solver::residual(int level, int arr_x, int arr_rhs, int arr_r, double *sumsq_out)
+{
+    if (!check_arr(arr_x, level, "mg_residual") || !check_arr(arr_rhs, level, "mg_residual")) return MG_ERR_BAD_ARG;
+    if (arr_r >= 0 && (!check_arr(arr_r, level, "mg_residual") || arr_r == arr_x || arr_r == arr_rhs)) {
+        set_last_error("mg_residual: bad output array");
+        return MG_ERR_BAD_ARG;
+    }
+    MG_HIP(hipSetDevice(device_));
+    int rc = d_.dtype == MG_F64 ? residual_t<double>(level, arr_x, arr_rhs, arr_r, true)
+                                : residual_t<float>(level, arr_x, arr_rhs, arr_r, true);
+    if (rc) return rc;
+    if (sumsq_out) {
+        MG_HIP(hipMemcpyAsync(h_scal_, d_scal_, sizeof(double), hipMemcpyDeviceToHost, stream_));
+        MG_HIP(hipStreamSynchronize(stream_));
+        *sumsq_out = h_scal_[0];
+    }
+    return MG_OK;
+}
+
+template <typename T>
+int Solver::sumsq_t(int level, int arr)
+{
+    launch_sumsq<T>(stream_, lv_[level].g, ptr<T>(arr, level), d_partials_, d_scal_ + 1);
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+}
+
+int Solver::sumsq(int level, int arr, double *out)
+{
+    if (!out || !check_arr(arr, level, "mg_sumsq")) return MG_ERR_BAD_ARG;
+    MG_HIP(hipSetDevice(device_));
+    int rc = d_.dtype == MG_F64 ? sumsq_t<double>(level, arr) : sumsq_t<float>(level, arr);
+    if (rc) return rc;
+    MG_HIP(hipMemcpyAsync(h_scal_ + 1, d_scal_ + 1, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    MG_HIP(hipStreamSynchronize(stream_));
+    *out = h_scal_[1];
+    return MG_OK;
+}
+
+template <typename T>
+int Solver::restrict_t(int fl, int kind, int as, int ad)
+{
+    if (kind == MG_RESTRICT_FULLW)
+        launch_restrict_fw<T>(stream_, lv_[fl].g, lv_[fl + 1].g, ptr<T>(as, fl), ptr<T>(ad, fl + 1));
+    else
+        launch_inject<T>(stream_, lv_[fl].g, lv_[fl + 1].g, ptr<T>(as, fl), ptr<T>(ad, fl + 1));
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+}
+
+int Solver::restrict_to(int fine_level, int kind, int arr_src, int arr_dst)
+{
+    if (fine_level + 1 >= d_.levels || !check_arr(arr_src, fine_level, "mg_restrict") ||
+        !check_arr(arr_dst, fine_level + 1, "mg_restrict")) {
+        set_last_error("mg_restrict: bad level / array");
+        return MG_ERR_BAD_ARG;
+    }
+    MG_HIP(hipSetDevice(device_));
+    return d_.dtype == MG_F64 ? restrict_t<double>(fine_level, kind, arr_src, arr_dst)
+                              : restrict_t<float>(fine_level, kind, arr_src, arr_dst);
+}
+
+template <typename T>
+int Solver::prolong_t(int cl, int add, int as, int ad)
+{
+    launch_prolong<T>(stream_, lv_[cl].g, lv_[cl - 1].g, ptr<T>(as, cl), ptr<T>(ad, cl - 1), add != 0);
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+}
+
+int Solver::prolong(int coarse_level, int add, int arr_src, int arr_dst)
+{
+    if (coarse_level < 1 || !check_arr(arr_src, coarse_level, "mg_prolong") ||
+        !check_arr(arr_dst, coarse_level - 1, "mg_prolong")) {
+        set_last_error("mg_prolong: bad level / array");
+        return MG_ERR_BAD_ARG;
+    }
+    MG_HIP(hipSetDevice(device_));
+    return d_.dtype == MG_F64 ? prolong_t<double>(coarse_level, add, arr_src, arr_dst)
+                              : prolong_t<float>(coarse_level, add, arr_src, arr_dst);
+}
+
+template <typename T>
+int Solver::correct_t(int au, int ae)
+{
+    launch_correct<T>(stream_, lv_[0].g, ptr<T>(au, 0), ptr<T>(ae, 0));
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+}
+
+int Solver::correct(int arr_u, int arr_e)
+{
+    if (!check_arr(arr_u, 0, "mg_correct") || !check_arr(arr_e, 0, "mg_correct") || arr_u == arr_e)
+        return MG_ERR_BAD_ARG;
+    MG_HIP(hipSetDevice(device_));
+    return d_.dtype == MG_F64 ? correct_t<double>(arr_u, arr_e) : correct_t<float>(arr_u, arr_e);
+}
+
+template <typename T>
+int Solver::coarse_t(int level, int ax, int ar)
+{
+    Level &L = lv_[level];
+    launch_coarse_solve<T>(stream_, L.g, coef_of<T>(L), (T)d_.omega, d_.smoother, ptr<T>(ax, level),
+                           ptr<T>(MG_ARR_TMP, level), ptr<T>(ar, level), d_.coarse_maxit,
+                           d_.coarse_tol, d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0, d_coarse_);
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+}
+
+int Solver::coarse_solve(int level, int arr_x, int arr_rhs, mg_cycle_stats *st)
+{
+    if (!check_arr(arr_x, level, "mg_coarse_solve") || !check_arr(arr_rhs, level, "mg_coarse_solve") ||
+        arr_x == MG_ARR_TMP || arr_rhs == MG_ARR_TMP || arr_x == arr_rhs)
+        return MG_ERR_BAD_ARG;
+    MG_HIP(hipSetDevice(device_));
+    int rc = d_.dtype == MG_F64 ? coarse_t<double>(level, arr_x, arr_rhs) : coarse_t<float>(level, arr_x, arr_rhs);
+    if (rc) return rc;
+    MG_HIP(hipMemcpyAsync(h_coarse_, d_coarse_, sizeof(CoarseOut), hipMemcpyDeviceToHost, stream_));
+    MG_HIP(hipStreamSynchronize(stream_));
+    if (st) {
+        st->coarse_iters = h_coarse_->iters;
+        st->coarse_flag = h_coarse_->flag;
+        st->coarse_relres = h_coarse_->relres;
+        st->fine_sumsq_r = 0;
+    }
+    return MG_OK;
+}
+
+#define MG_TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// Standard V(nu_pre, nu_post) (extension, BASELINE configs 2-4)
+template <typename T>
+int Solver::vcycle_rec_t(int l)
+{
+    const int L = d_.levels;
+    if (l == L - 1) return coarse_t<T>(l, MG_ARR_U, MG_ARR_RHS);
+    MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS));
+    MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
+    MG_TRY(restrict_t<T>(l, d_.restriction, MG_ARR_TMP, MG_ARR_RHS));
+    MG_TRY(zero_array(MG_ARR_U, l + 1));
+    MG_TRY(vcycle_rec_t<T>(l + 1));
+    MG_TRY(prolong_t<T>(l + 1, 1, MG_ARR_U, MG_ARR_U));
+    MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS));
+    return MG_OK;
+}
+
+// Enqueues one cycle; no host synchronisation inside.
+template <typename T>
+int Solver::cycle_enqueue_t()
+{
+    const int L = d_.levels;
+    if (d_.cycle == MG_CYCLE_V) return vcycle_rec_t<T>(0);
+    // --- reference sawtooth, include/multigrid.hpp:126-145 ---
+    // :127  sol * RES : fine residual into `res`, sum r^2
+    MG_TRY(residual_t<T>(0, MG_ARR_U, MG_ARR_RHS, MG_ARR_RES, true));
+    MG_HIP(hipMemcpyAsync(d_scal_ + 2, d_scal_, sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    // every level's rhs is the fine residual seen through mask() (:113,121) = injection
+    int src = MG_ARR_RES;
+    for (int l = 0; l + 1 < L; l++) { MG_TRY(restrict_t<T>(l, MG_RESTRICT_INJECT, src, MG_ARR_RHS)); src = MG_ARR_RHS; }
+    const int rhsL = (L == 1) ? MG_ARR_RES : MG_ARR_RHS;
+    // :128-131 coarse solve from err == 0
+    MG_TRY(zero_array(MG_ARR_E, L - 1));
+    MG_TRY(coarse_t<T>(L - 1, MG_ARR_E, rhsL));
+    // :134-139 prolong (overwrite) + nu sweeps, coarse to fine
+    for (int l = L - 2; l >= 0; l--) {
+        MG_TRY(prolong_t<T>(l + 1, 0, MG_ARR_E, MG_ARR_E));
+        MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_E, l == 0 ? MG_ARR_RES : MG_ARR_RHS));
+    }
+    // :141-144
+    MG_TRY(correct_t<T>(MG_ARR_U, MG_ARR_E));
+    return MG_OK;
+}
+
+int Solver::cycle_enqueue()
+{
+    return d_.dtype == MG_F64 ? cycle_enqueue_t<double>() : cycle_enqueue_t<float>();
+}
+
+int Solver::cycle(mg_cycle_stats *st)
+{
+    MG_HIP(hipSetDevice(device_));
+    MG_TRY(cycle_enqueue());
+    MG_HIP(hipMemcpyAsync(h_coarse_, d_coarse_, sizeof(CoarseOut), hipMemcpyDeviceToHost, stream_));
+    MG_HIP(hipMemcpyAsync(h_scal_ + 2, d_scal_ + 2, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    MG_HIP(hipStreamSynchronize(stream_));
+    if (st) {
+        st->coarse_iters = h_coarse_->iters;
+        st->coarse_flag = h_coarse_->flag;
+        st->coarse_relres = h_coarse_->relres;
+        st->fine_sumsq_r = (d_.cycle == MG_CYCLE_SAWTOOTH) ? h_scal_[2] : 0.0;
+    }
+    return MG_OK;
+}
+
+int Solver::cycle_async(int count)
+{
+    MG_HIP(hipSetDevice(device_));
+    for (int i = 0; i < count; i++) MG_TRY(cycle_enqueue());
+    return MG_OK;
+}
+
+// Outer loop of src/main.cpp:72-116.
+int Solver::solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist,
+                  mg_cycle_stats *per_cycle)
+{
+    MG_HIP(hipSetDevice(device_));
+    double nb = 0, nr = 0;
+    MG_TRY(sumsq(0, MG_ARR_RHS, &nb));                       // Residual ctor, solvers.hpp:237-242
+    MG_TRY(residual(0, MG_ARR_U, MG_ARR_RHS, -1, &nr));      // main.cpp:73-74
+    int nh = 0;
+    if (hist && nh < hist_cap) hist[nh] = std::sqrt(nr / nb);
+    nh++;
+    for (int it = 0; it < maxit; it++) {
+        if (d_.outer_pre_gs > 0)                             // `u * GS * GS` main.cpp:85
+            MG_TRY(smooth(0, MG_SMOOTH_GS_LEX, d_.outer_pre_gs, MG_ARR_U, MG_ARR_RHS));
+        MG_TRY(cycle(per_cycle ? &per_cycle[it] : nullptr));  // `* MGx`
+        MG_TRY(residual(0, MG_ARR_U, MG_ARR_RHS, -1, &nr));  // main.cpp:86
+        double rel = std::sqrt(nr / nb);
+        if (hist && nh < hist_cap) hist[nh] = rel;
+        nh++;
+        if (rel <= tol) break;                               // main.cpp:88-89
+    }
+    if (n_hist) *n_hist = nh;
+    return MG_OK;
+}
+
+int Solver::sync()
+{
+    MG_HIP(hipSetDevice(device_));
+    MG_HIP(hipStreamSynchronize(stream_));
+    return MG_OK;
+}
+
+int Solver::timer_start()
+{
+    MG_HIP(hipSetDevice(device_));
+    MG_HIP(hipEventRecord(ev0_, stream_));
+    return MG_OK;
+}
+
+int Solver::timer_stop(double *ms)
+{
+    MG_HIP(hipSetDevice(device_));
+    MG_HIP(hipEventRecord(ev1_, stream_));
+    MG_HIP(hipEventSynchronize(ev1_));
+    float f = 0;
+    MG_HIP(hipEventElapsedTime(&f, ev0_, ev1_));
+    if (ms) *ms = (double)f;
+    return MG_OK;
+}
+
+}  // namespace mg

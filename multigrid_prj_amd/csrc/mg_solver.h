@@ -1,0 +1,98 @@
+// mg_solver.h -- host-side owner of the HBM-resident grid hierarchy and the
+// stream-ordered cycle drivers behind the C-ABI of include/mg_hip.h.
+#ifndef MG_SOLVER_H
+#define MG_SOLVER_H
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mg_hip.h"
+#include "mg_geom.h"
+
+namespace mg {
+
+void set_last_error(const std::string &msg);
+const std::string &last_error();
+int validate_desc(const mg_desc *d, std::string *why);
+int level_n(const mg_desc &d, int level);
+void level_coefficients(const mg_desc &d, int level, double out[4]);
+
+struct SlabPlan {
+    int z0 = 0, nz = 0;           // owned planes of this rank on the level
+    int first_gathered_level = 0;  // levels >= this live on rank 0 only
+};
+// host-only partition arithmetic (no HIP call), shared by the library and the CPU tests
+int plan_slab(const mg_desc &d, int nranks, int rank, int level, SlabPlan *out, std::string *why);
+
+constexpr int NUM_ARR = 5;
+
+struct Level {
+    Geom g{};
+    size_t alloc_elems = 0;      // (nz + 2) * plane
+    void *base[NUM_ARR] = {};    // allocations (ghost plane first)
+    double coef[4] = {};
+    bool present = true;         // false: level not held by this rank (gathered elsewhere)
+};
+
+class Solver {
+public:
+    Solver(const mg_desc &d, int device);
+    ~Solver();
+    int init();  // allocates; returns mg_status
+
+    int set_array(int which, int level, const void *host);
+    int get_array(int which, int level, void *host);
+    int zero_array(int which, int level);
+
+    int smooth(int level, int smoother, int sweeps, int arr_x, int arr_rhs);
+    int residual(int level, int arr_x, int arr_rhs, int arr_r, double *sumsq);
+    int sumsq(int level, int arr, double *out);
+    int restrict_to(int fine_level, int kind, int arr_src, int arr_dst);
+    int prolong(int coarse_level, int add, int arr_src, int arr_dst);
+    int correct(int arr_u, int arr_e);
+    int coarse_solve(int level, int arr_x, int arr_rhs, mg_cycle_stats *st);
+    int cycle(mg_cycle_stats *st);
+    int cycle_async(int count);
+    int solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist,
+              mg_cycle_stats *per_cycle);
+    int sync();
+    int timer_start();
+    int timer_stop(double *ms);
+    size_t device_bytes() const { return bytes_; }
+
+    const mg_desc &desc() const { return d_; }
+    int nlevels() const { return d_.levels; }
+    const Level &level(int l) const { return lv_[l]; }
+
+private:
+    template <typename T> T *ptr(int which, int level) const;  // local plane 0
+    template <typename T> int smooth_t(int level, int smoother, int sweeps, int ax, int ar);
+    template <typename T> int residual_t(int level, int ax, int ar, int arr_r, bool want_norm);
+    template <typename T> int sumsq_t(int level, int arr);
+    template <typename T> int restrict_t(int fl, int kind, int as, int ad);
+    template <typename T> int prolong_t(int cl, int add, int as, int ad);
+    template <typename T> int correct_t(int au, int ae);
+    template <typename T> int coarse_t(int level, int ax, int ar);
+    template <typename T> int cycle_enqueue_t();
+    template <typename T> int vcycle_rec_t(int l);
+    int cycle_enqueue();
+    bool check_arr(int which, int level, const char *fn) const;
+    size_t esize() const { return d_.dtype == MG_F64 ? 8 : 4; }
+
+    mg_desc d_;
+    int device_;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    std::vector<Level> lv_;
+    double *d_partials_ = nullptr;  // per-block partial sums
+    double *d_scal_ = nullptr;      // [0] sum r^2, [1] sum b^2, [2] cycle's fine sum r^2
+    CoarseOut *d_coarse_ = nullptr;
+    double *h_scal_ = nullptr;      // pinned mirrors
+    CoarseOut *h_coarse_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+}  // namespace mg
+#endif

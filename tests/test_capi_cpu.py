@@ -1,0 +1,87 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/mg_hip.h
+declares, refuses to run without a GPU (no CPU fallback), and its host-only logic
+(descriptor validation, slab partition plan) is right.  No compute calls here."""
+import os
+import re
+
+import pytest
+
+from multigrid_prj_amd import capi
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mg_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mg_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"libmg_hip.so does not export {name}"
+    assert sorted(capi.EXPORTS) == declared
+
+
+def test_no_cpu_fallback():
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.MgError) as e:
+        capi.Solver(capi.make_desc(dim=2, n=17, levels=2))
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_descriptor_validation_messages():
+    lib = capi.load()
+    import ctypes as C
+    for bad in (dict(n=200, levels=2), dict(n=17, levels=5), dict(dim=4), dict(n=17, levels=2, alpha=-1.0)):
+        h = C.c_void_p()
+        rc = lib.mg_create(C.byref(capi.make_desc(**bad)), -1, C.byref(h))
+        assert rc == -1 and not h.value and lib.mg_last_error()
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "multigrid_prj_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                src = open(os.path.join(dp, f)).read()
+                # comments may name the oracle; code must never import, include, link or load it
+                assert not re.search(r"(import\s+oracle|from\s+oracle|#include.*oracle|liboracle|pyoracle|orc_[a-z])", src), \
+                    f"{f} uses the oracle"
+
+
+@pytest.mark.parametrize("n,levels,nranks", [(513, 6, 8), (513, 6, 4), (513, 6, 2), (1025, 7, 8), (257, 5, 8), (129, 3, 3)])
+def test_slab_plan_partitions_every_level(n, levels, nranks):
+    d = capi.make_desc(dim=3, n=n, levels=levels)
+    fg = capi.plan_slab(d, nranks, 0, 0)[2]
+    assert 1 <= fg <= levels
+    for l in range(levels):
+        nl = ((n - 1) >> l) + 1
+        covered = 0
+        for r in range(nranks):
+            z0, nz, fg_r = capi.plan_slab(d, nranks, r, l)
+            assert fg_r == fg
+            if l >= fg:
+                assert (z0, nz) == ((0, nl) if r == 0 else (0, 0))
+                continue
+            assert z0 == covered and nz >= 2
+            covered += nz
+            if l + 1 < fg:  # coarse plane K lives with fine plane 2K
+                zc, nzc, _ = capi.plan_slab(d, nranks, r, l + 1)
+                assert z0 == 2 * zc
+                assert all(z0 <= 2 * k < z0 + nz for k in range(zc, zc + nzc))
+        if l < fg:
+            assert covered == nl
+
+
+def test_slab_plan_single_rank_and_errors():
+    d = capi.make_desc(dim=3, n=65, levels=3)
+    assert capi.plan_slab(d, 1, 0, 0) == (0, 65, 3)
+    with pytest.raises(capi.MgError):
+        capi.plan_slab(d, 64, 0, 0)  # too many ranks for the grid
+    with pytest.raises(capi.MgError):
+        capi.plan_slab(capi.make_desc(dim=2, n=65, levels=3), 2, 0, 0)
