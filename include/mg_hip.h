@@ -114,6 +114,12 @@ int mg_sync(mg_handle h);
 /* HIP-event timing on the handle's own stream (torch.cuda.Event would not see it) */
 int mg_timer_start(mg_handle h);
 int mg_timer_stop(mg_handle h, double *milliseconds);
+/* In-region kernel timing for bench.py: between begin and end every finest-grid
+ * smoother call made by mg_cycle/mg_cycle_async/mg_smooth is bracketed by HIP events on
+ * the handle's stream. end synchronises and returns the summed time and the number of
+ * sweeps (kernel launches; a red-black sweep counts once, both colours included). */
+int mg_profile_begin(mg_handle h);
+int mg_profile_end(mg_handle h, double *smoother_ms, int *smoother_sweeps);
 /* bytes of HBM held by the handle */
 int mg_device_bytes(mg_handle h, size_t *bytes);
 

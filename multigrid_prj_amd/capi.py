@@ -71,7 +71,7 @@ EXPORTS = [
     "mg_level_coefficients", "mg_set_rhs", "mg_set_solution", "mg_get_solution", "mg_set_array",
     "mg_get_array", "mg_zero_array", "mg_smooth", "mg_residual", "mg_sumsq", "mg_restrict",
     "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_cycle", "mg_cycle_async", "mg_solve",
-    "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_device_bytes", "mg_comm_unique_id",
+    "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_device_bytes", "mg_comm_unique_id",
     "mg_create_distributed", "mg_plan_slab",
 ]
 
@@ -115,6 +115,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.mg_sync.argtypes = [vp]
     L.mg_timer_start.argtypes = [vp]
     L.mg_timer_stop.argtypes = [vp, dp]
+    L.mg_profile_begin.argtypes = [vp]
+    L.mg_profile_end.argtypes = [vp, dp, C.POINTER(i)]
     L.mg_device_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.mg_comm_unique_id.argtypes = [vp]
     L.mg_create_distributed.argtypes = [C.POINTER(MgDesc), i, i, i, vp, C.POINTER(vp)]
@@ -252,6 +254,13 @@ class Solver:
 
     def timer_stop(self) -> float:
         ms = C.c_double(0); _check(self.lib.mg_timer_stop(self.h, C.byref(ms))); return ms.value
+
+    def profile_begin(self): _check(self.lib.mg_profile_begin(self.h))
+
+    def profile_end(self):
+        """-> (summed ms of the finest-grid smoother calls, number of sweeps)"""
+        ms = C.c_double(0); n = C.c_int(0)
+        _check(self.lib.mg_profile_end(self.h, C.byref(ms), C.byref(n))); return ms.value, n.value
 
     def device_bytes(self) -> int:
         b = C.c_size_t(0); _check(self.lib.mg_device_bytes(self.h, C.byref(b))); return b.value

@@ -1,4 +1,275 @@
-// mg_jacobi_fast.hip -- finest-grid fast paths (filled in after microbenchmarks).
+// mg_jacobi_fast.hip -- finest-grid fast path for the 7-point sweeps (Jacobi update and
+// residual), gfx950.  Design chosen with tools/kbench.hip on MI355X:
+//
+//  * one lane owns one aligned 16-byte vector of x (2 doubles / 4 floats); a wave64 covers
+//    128 / 256 consecutive x of RY = 2 rows; BW = 4 waves are stacked in y;
+//  * the workgroup marches ZC = 3 planes in z with the (z-1, z, z+1) values of its columns
+//    in registers: every u value is loaded once per workgroup column, the rest of the
+//    7-point neighbourhood comes from registers (z, in-wave y), DPP whole-wave shifts (x)
+//    and two y-halo rows that hit L1/L2; short ZC keeps concurrently running workgroups
+//    on a few adjacent planes (DRAM-page friendly), the z-halo planes come from L2/MALL;
+//  * XCD-aware block order: blockIdx -> (blockIdx % 8) * chunk + blockIdx / 8, so each
+//    XCD (own L2) sweeps a contiguous range of rows/planes and y/z-halo re-reads stay in
+//    that L2;
+//  * non-temporal stores (and non-temporal rhs loads on levels larger than the caches):
+//    the output and rhs streams have no reuse inside a sweep;
+//  * the odd last column (n = 2^k+1) is written as ONE full 128-byte line (boundary value
+//    + the row's zero padding): an 8-byte partial-line store per row costs ~5 % of the
+//    sweep on HBM3E;
+//  * arithmetic order, -ffp-contract=off and IEEE division are those of mg_kernels.hip:
+//    results are bit-identical to the generic kernels and to the oracle.
+// MFMA is not used: there is no contraction here, the kernel is HBM-bound (24 B/point).
 #include "mg_kernels.h"
+
 namespace mg {
+namespace {
+
+template <typename T> struct VecOf;
+template <> struct VecOf<double> { static constexpr int V = 2; typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<float> { static constexpr int V = 4; typedef float type __attribute__((ext_vector_type(4))); };
+
+// lane i <- lane i-1 (lane 0 keeps `edge`) : DPP wave_shr:1
+__device__ __forceinline__ float from_prev_lane(float v, float edge)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
+__device__ __forceinline__ double from_prev_lane(double v, double edge)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// lane i <- lane i+1 (lane 63 keeps `edge`) : DPP wave_shl:1
+__device__ __forceinline__ float from_next_lane(float v, float edge)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double from_next_lane(double v, double edge)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+enum { OP_JACOBI = 0, OP_RESIDUAL = 1 };
+
+constexpr int RY = 2, BW = 4, ZC = 3;
+
+// OP_JACOBI : out = Jacobi update (DAMPED selects omega != 1)
+// OP_RESIDUAL: out = rhs - A u (stored if SAVE), sum r^2 -> partials[block] if NORM
+template <typename T, int OP, bool DAMPED, bool SAVE, bool NORM, bool NTLOAD>
+__global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
+                                                     const T *__restrict__ u,
+                                                     const T *__restrict__ rhs, T *__restrict__ out,
+                                                     double *__restrict__ partials, int nbx, int nby,
+                                                     int nbz)
+{
+    constexpr int V = VecOf<T>::V;
+    typedef typename VecOf<T>::type vec;
+    __shared__ double sh[BW];
+
+    const int nblocks = nbx * nby * nbz;
+    const int per = (nblocks + 7) >> 3;
+    const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double sq = 0.;
+    if (bid < nblocks) {
+        const int bx = bid % nbx, by = (bid / nbx) % nby, bz = bid / (nbx * nby);
+        const int nvec = g.nx / V;
+        const int x0 = V * (bx * 64 + lane);
+        const bool xin = x0 < V * nvec;
+        const int x0c = min(x0, g.pitch - V);  // clamped for loads: every lane stays active
+        const int yb = (by * BW + wv) * RY;
+        const int z0 = bz * ZC;
+        const int zend = min(z0 + ZC, g.nz);
+        // does this wave hold the last full vector of the row? then it also writes column nx-1
+        const bool tailwave = (g.nx % V == 1) && (bx * 64 * V <= g.nx - 1 - V) && (g.nx - 1 - V < (bx + 1) * 64 * V);
+
+        long long rowoff[RY];
+        bool yin[RY], ybnd[RY];
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            int y = yb + r;
+            yin[r] = y < g.ny;
+            int yc = min(y, g.ny - 1);
+            ybnd[r] = (yc == 0) || (yc == g.ny - 1);
+            rowoff[r] = (long long)yc * g.pitch + x0c;
+        }
+        const long long off_lo = (long long)max(yb - 1, 0) * g.pitch + x0c;
+        const long long off_hi = (long long)min(yb + RY, g.ny - 1) * g.pitch + x0c;
+
+        vec zm[RY], cc[RY], zp[RY];
+        const T *pz = u + (long long)z0 * g.plane;
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            zm[r] = *(const vec *)(pz - g.plane + rowoff[r]);
+            cc[r] = *(const vec *)(pz + rowoff[r]);
+        }
+        for (int z = z0; z < zend; z++, pz += g.plane) {
+            const long long zo = (long long)z * g.plane;
+            vec b[RY];
+#pragma unroll
+            for (int r = 0; r < RY; r++) {
+                zp[r] = *(const vec *)(pz + g.plane + rowoff[r]);
+                if (NTLOAD) b[r] = __builtin_nontemporal_load((const vec *)(rhs + zo + rowoff[r]));
+                else b[r] = *(const vec *)(rhs + zo + rowoff[r]);
+            }
+            const vec hlo = *(const vec *)(pz + off_lo);
+            const vec hhi = *(const vec *)(pz + off_hi);
+            const int gz = g.gz0 + z;
+            const bool zb = (gz == 0) || (gz == g.gnz - 1);
+#pragma unroll
+            for (int r = 0; r < RY; r++) {
+                T el = 0, er = 0;
+                if (lane == 0) el = pz[rowoff[r] - 1];
+                if (lane == 63) er = pz[rowoff[r] + V];
+                const T xm = from_prev_lane(cc[r][V - 1], el);
+                const T xp = from_next_lane(cc[r][0], er);
+                const vec ym = (r > 0) ? cc[r > 0 ? r - 1 : 0] : hlo;
+                const vec yp = (r < RY - 1) ? cc[r < RY - 1 ? r + 1 : 0] : hhi;
+                const bool rb = zb || ybnd[r];
+                vec res;
+#pragma unroll
+                for (int e = 0; e < V; e++) {
+                    const T left = (e == 0) ? xm : cc[r][e > 0 ? e - 1 : 0];
+                    const T right = (e == V - 1) ? xp : cc[r][e < V - 1 ? e + 1 : 0];
+                    const bool bnd = rb || (x0 + e == 0) || (x0 + e == g.nx - 1);
+                    T sum = 0;
+                    sum += c.cz * zm[r][e];
+                    sum += c.cy * ym[e];
+                    sum += c.cx * left;
+                    if (OP == OP_RESIDUAL) sum += c.cd * cc[r][e];
+                    sum += c.cx * right;
+                    sum += c.cy * yp[e];
+                    sum += c.cz * zp[r][e];
+                    if (OP == OP_JACOBI) {
+                        T jac = (b[r][e] - sum) / c.cd;
+                        if (DAMPED) jac = cc[r][e] + omega * (jac - cc[r][e]);
+                        res[e] = bnd ? b[r][e] : jac;
+                    } else {
+                        if (bnd) sum = (T)1 * cc[r][e];
+                        res[e] = b[r][e] - sum;
+                    }
+                }
+                if (xin && yin[r]) {
+                    if (OP == OP_JACOBI || SAVE) __builtin_nontemporal_store(res, (vec *)(out + zo + rowoff[r]));
+                    if (NORM) {
+#pragma unroll
+                        for (int e = 0; e < V; e++) sq += (double)res[e] * (double)res[e];
+                    }
+                }
+                if (tailwave && lane >= 56 && yin[r]) {
+                    // column nx-1 (Dirichlet) as one full 128-byte line: value + zero padding
+                    const int j = lane - 56;
+                    constexpr int LINE = 128 / (int)sizeof(T);
+                    const int xs = g.nx - 1 + V * j;
+                    const int line_end = ((g.nx - 1) / LINE + 1) * LINE;
+                    const long long ro = zo + (rowoff[r] - x0c);
+                    T tb = 0, tres = 0;
+                    if (j == 0) {
+                        tb = rhs[ro + g.nx - 1];
+                        tres = (OP == OP_JACOBI) ? tb : tb - (T)1 * pz[(rowoff[r] - x0c) + g.nx - 1];
+                        if (NORM) sq += (double)tres * (double)tres;
+                    }
+                    if (xs < line_end && (OP == OP_JACOBI || SAVE)) {
+                        vec tv = (vec)(0);
+                        tv[0] = tres;
+                        __builtin_nontemporal_store(tv, (vec *)(out + ro + xs));
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RY; r++) { zm[r] = cc[r]; cc[r] = zp[r]; }
+        }
+    }
+    if (NORM) {
+        sq = wave_sum64(sq);
+        if (lane == 0) sh[wv] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0;
+            for (int w = 0; w < BW; w++) s += sh[w];
+            partials[blockIdx.x] = s;
+        }
+    }
+}
+
+struct FastGrid { int nbx, nby, nbz, grid; };
+template <typename T>
+FastGrid fast_grid(const Geom &g)
+{
+    constexpr int V = VecOf<T>::V;
+    FastGrid f;
+    f.nbx = (g.nx / V + 63) / 64;
+    f.nby = (g.ny + RY * BW - 1) / (RY * BW);
+    f.nbz = (g.nz + ZC - 1) / ZC;
+    int nblocks = f.nbx * f.nby * f.nbz;
+    f.grid = ((nblocks + 7) / 8) * 8;
+    return f;
+}
+
+}  // namespace
+
+template <typename T>
+bool fast_path_ok(const Geom &g)
+{
+    constexpr int V = VecOf<T>::V;
+    // 3-D, rows long enough to fill a wave, at most the one boundary column left over
+    return g.dim == 3 && g.nx >= 33 && (g.nx % V) <= 1 && g.ny >= 3;
+}
+
+template <typename T>
+int fast_partials_capacity(const Geom &g)
+{
+    return fast_path_ok<T>(g) ? fast_grid<T>(g).grid : 0;
+}
+
+// arrays larger than this stream through the caches: use non-temporal rhs loads
+static bool stream_level(const Geom &g, size_t esize) { return (size_t)g.nz * g.plane * esize >= (size_t)64 << 20; }
+
+template <typename T>
+void launch_jacobi_fast(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u,
+                        const T *rhs, T *out)
+{
+    FastGrid f = fast_grid<T>(g);
+    const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
+    dim3 gr(f.grid), bl(64 * BW);
+#define MG_J(D, N) hipLaunchKernelGGL((k_sweep3d<T, OP_JACOBI, D, true, false, N>), gr, bl, 0, s, g, c, omega, u, rhs, out, (double *)nullptr, f.nbx, f.nby, f.nbz)
+    if (damped) { if (nt) MG_J(true, true); else MG_J(true, false); }
+    else { if (nt) MG_J(false, true); else MG_J(false, false); }
+#undef MG_J
+}
+
+// returns the number of per-block partials written (0 when no norm was requested)
+template <typename T>
+int launch_residual_fast(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs,
+                         T *r, double *d_partials, bool want_norm)
+{
+    FastGrid f = fast_grid<T>(g);
+    const bool nt = stream_level(g, sizeof(T));
+    dim3 gr(f.grid), bl(64 * BW);
+#define MG_R(S, NO, N) hipLaunchKernelGGL((k_sweep3d<T, OP_RESIDUAL, false, S, NO, N>), gr, bl, 0, s, g, c, (T)1, u, rhs, r, d_partials, f.nbx, f.nby, f.nbz)
+    if (r && want_norm) { if (nt) MG_R(true, true, true); else MG_R(true, true, false); }
+    else if (r) { if (nt) MG_R(true, false, true); else MG_R(true, false, false); }
+    else { if (nt) MG_R(false, true, true); else MG_R(false, true, false); }
+#undef MG_R
+    return want_norm ? f.grid : 0;
+}
+
+template bool fast_path_ok<double>(const Geom &);
+template bool fast_path_ok<float>(const Geom &);
+template int fast_partials_capacity<double>(const Geom &);
+template int fast_partials_capacity<float>(const Geom &);
+template void launch_jacobi_fast<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *);
+template void launch_jacobi_fast<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *);
+template int launch_residual_fast<double>(hipStream_t, const Geom &, const Coef<double> &, const double *, const double *, double *, double *, bool);
+template int launch_residual_fast<float>(hipStream_t, const Geom &, const Coef<float> &, const float *, const float *, float *, double *, bool);
+
+}  // namespace mg

@@ -15,6 +15,17 @@ template <typename T>
 void launch_jacobi(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u,
                    const T *rhs, T *out);
 
+// finest-grid fast paths (mg_jacobi_fast.hip); launch_jacobi / launch_residual pick them
+// automatically when fast_path_ok<T>(g)
+template <typename T> bool fast_path_ok(const Geom &g);
+template <typename T> int fast_partials_capacity(const Geom &g);
+template <typename T>
+void launch_jacobi_fast(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u,
+                        const T *rhs, T *out);
+template <typename T>
+int launch_residual_fast(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs,
+                         T *r, double *d_partials, bool want_norm);
+
 // one colour half-sweep of red-black Gauss-Seidel, in place
 template <typename T>
 void launch_rbgs_colour(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u,

@@ -16,7 +16,11 @@
 // is priced against the HBM roofline.
 #include "mg_kernels.h"
 
+#include <algorithm>
+
 namespace mg {
+
+using std::max;
 
 namespace {
 
@@ -469,13 +473,17 @@ inline dim3 grid_for(int nx, int ny, int nz)
 int reduce_partials_capacity(const Geom &g)
 {
     dim3 gr = grid_for(g.nx, g.ny, g.nz);
-    return (int)(gr.x * gr.y * gr.z);
+    int cap = (int)(gr.x * gr.y * gr.z);
+    cap = max(cap, fast_partials_capacity<double>(g));
+    cap = max(cap, fast_partials_capacity<float>(g));
+    return cap;
 }
 
 template <typename T>
 void launch_jacobi(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u,
                    const T *rhs, T *out)
 {
+    if (fast_path_ok<T>(g)) { launch_jacobi_fast<T>(s, g, c, omega, u, rhs, out); return; }
     dim3 gr = grid_for(g.nx, g.ny, g.nz), bl(BX, BY, 1);
     const bool damped = (omega != (T)1);
     if (g.dim == 3) {
@@ -508,6 +516,11 @@ void launch_residual(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
                      T *r, double *d_partials, double *d_sumsq)
 {
     // d_sumsq == nullptr: residual vector only (V-cycle restriction input), no norm
+    if (fast_path_ok<T>(g)) {
+        int np = launch_residual_fast<T>(s, g, c, u, rhs, r, d_partials, d_sumsq != nullptr);
+        if (d_sumsq) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, d_partials, (long long)np, d_sumsq);
+        return;
+    }
     dim3 gr = grid_for(g.nx, g.ny, g.nz), bl(BX, BY, 1);
     long long nb = (long long)gr.x * gr.y * gr.z;
 #define MG_RES(DIM, SAVE, NORM) \

@@ -117,6 +117,7 @@ Solver::~Solver()
     if (d_coarse_) (void)hipFree(d_coarse_);
     if (h_scal_) (void)hipHostFree(h_scal_);
     if (h_coarse_) (void)hipHostFree(h_coarse_);
+    for (auto &e : prof_ev_) (void)hipEventDestroy(e);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -231,6 +232,15 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar)
 {
     Level &L = lv_[level];
     Coef<T> c = coef_of<T>(L);
+    const bool prof = profiling_ && level == 0 && sweeps > 0 && smoother != MG_SMOOTH_GS_LEX;
+    if (prof) {
+        if (prof_used_ + 2 > prof_ev_.size()) {
+            size_t old = prof_ev_.size();
+            prof_ev_.resize(old + 256);
+            for (size_t i = old; i < prof_ev_.size(); i++) MG_HIP(hipEventCreate(&prof_ev_[i]));
+        }
+        MG_HIP(hipEventRecord(prof_ev_[prof_used_], stream_));
+    }
     switch (smoother) {
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
@@ -249,6 +259,11 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar)
     default:
         if (sweeps > 0) launch_gs_lex<T>(stream_, L.g, c, sweeps, ptr<T>(ax, level), ptr<T>(ar, level));
         break;
+    }
+    if (prof) {
+        MG_HIP(hipEventRecord(prof_ev_[prof_used_ + 1], stream_));
+        prof_used_ += 2;
+        prof_sweeps_ += sweeps;
     }
     MG_HIP(hipGetLastError());
     return MG_OK;
@@ -508,6 +523,30 @@ int Solver::sync()
 {
     MG_HIP(hipSetDevice(device_));
     MG_HIP(hipStreamSynchronize(stream_));
+    return MG_OK;
+}
+
+int Solver::profile_begin()
+{
+    profiling_ = true;
+    prof_used_ = 0;
+    prof_sweeps_ = 0;
+    return MG_OK;
+}
+
+int Solver::profile_end(double *ms, int *sweeps)
+{
+    MG_HIP(hipSetDevice(device_));
+    MG_HIP(hipStreamSynchronize(stream_));
+    profiling_ = false;
+    double tot = 0;
+    for (size_t i = 0; i + 1 < prof_used_; i += 2) {
+        float f = 0;
+        MG_HIP(hipEventElapsedTime(&f, prof_ev_[i], prof_ev_[i + 1]));
+        tot += f;
+    }
+    if (ms) *ms = tot;
+    if (sweeps) *sweeps = prof_sweeps_;
     return MG_OK;
 }
 

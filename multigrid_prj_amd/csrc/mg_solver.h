@@ -60,6 +60,8 @@ public:
     int sync();
     int timer_start();
     int timer_stop(double *ms);
+    int profile_begin();
+    int profile_end(double *ms, int *sweeps);
     size_t device_bytes() const { return bytes_; }
 
     const mg_desc &desc() const { return d_; }
@@ -92,6 +94,11 @@ private:
     double *h_scal_ = nullptr;      // pinned mirrors
     CoarseOut *h_coarse_ = nullptr;
     size_t bytes_ = 0;
+    // in-region timing of the finest-grid smoother (mg_profile_begin/end)
+    bool profiling_ = false;
+    std::vector<hipEvent_t> prof_ev_;
+    size_t prof_used_ = 0;
+    int prof_sweeps_ = 0;
 };
 
 }  // namespace mg

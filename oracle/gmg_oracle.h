@@ -63,6 +63,8 @@ typedef struct orc_coef_f32 { float cx, cy, cz, cd; } orc_coef_f32;
     void orc_rbgs_##SUF(int dim, int n, orc_coef_##SUF c, REAL *u, const REAL *rhs);         \
     double orc_residual_##SUF(int dim, int n, orc_coef_##SUF c, const REAL *u,               \
                               const REAL *rhs, REAL *r);                                     \
+    void orc_residual_vec_##SUF(int dim, int n, orc_coef_##SUF c, const REAL *u,             \
+                                const REAL *rhs, REAL *r);                                   \
     double orc_sumsq_##SUF(size_t count, const REAL *v);                                     \
     void orc_inject_##SUF(int dim, int nc, const REAL *fine, REAL *coarse);                  \
     void orc_restrict_fw_##SUF(int dim, int nc, const REAL *fine, REAL *coarse);             \

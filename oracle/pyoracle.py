@@ -84,9 +84,20 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _default_threads() -> int:
+    """A GPU box reports every host thread but grants a 16-CPU share per GPU: more OpenMP
+    threads than that only oversubscribes."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_NUM_THREADS", str(_default_threads()))
         build()
         L = C.CDLL(_LIB_PATH)
         L.orc_validate.argtypes = [C.POINTER(MgDesc)]

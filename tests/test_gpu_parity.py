@@ -43,6 +43,10 @@ CASES = [
     dict(dim=3, n=67, levels=2, dtype=capi.MG_F64, alpha=1.0, length=1.0),
     dict(dim=3, n=129, levels=4, dtype=capi.MG_F64, alpha=1.0, length=1.0),
     dict(dim=3, n=131, levels=2, dtype=capi.MG_F32, alpha=1.0, length=1.0),
+    # fast-path shapes (mg_jacobi_fast.hip): n % 4 == 1 in fp32, odd n in fp64
+    dict(dim=3, n=65, levels=3, dtype=capi.MG_F32, alpha=1.0, length=1.0),
+    dict(dim=3, n=129, levels=2, dtype=capi.MG_F32, alpha=3.0, length=2.0),
+    dict(dim=3, n=97, levels=2, dtype=capi.MG_F64, alpha=1.0, length=1.0),
 ]
 IDS = [f"{c['dim']}d-n{c['n']}-L{c['levels']}-{'f64' if c['dtype'] == 0 else 'f32'}" for c in CASES]
 
@@ -186,7 +190,11 @@ def test_vcycle_extension(case):
         assert np.array_equal(sg.get_solution(), so.get_solution())
         hg, _ = sg.solve(1e-9, 4); ho, _ = so.solve(1e-9, 4)
         np.testing.assert_allclose(hg, ho, rtol=1e-10 if case["dtype"] == 0 else 1e-4)
-        assert hg[-1] < 0.2 * hg[0]  # it is a multigrid cycle: it converges fast
+        # Injection right after a red-black sweep aliases (the residual vanishes on the last
+        # colour), a textbook failure both implementations reproduce; every other pairing
+        # must converge like a multigrid cycle.
+        if not (case["smoother"] == capi.SMOOTH_RBGS and case.get("restriction", 0) == capi.RESTRICT_INJECT):
+            assert hg[-1] < 0.2 * hg[0]
 
 
 with open(os.path.join(G, "ref_solve.json")) as _f:
