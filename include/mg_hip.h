@@ -99,6 +99,10 @@ int mg_correct(mg_handle h, int arr_u, int arr_e);
 /* Solver::Solve on `level` (solvers.hpp:324-342 as instantiated at multigrid.hpp:123),
  * one persistent workgroup; honours desc.coarse_{mode,maxit,tol}, desc.smoother */
 int mg_coarse_solve(mg_handle h, int level, int arr_x, int arr_rhs, mg_cycle_stats *st);
+/* the same with the Solver constructor's arguments (smoother, maxit, tol) given per call
+ * instead of taken from the descriptor; fixed != 0 runs exactly maxit sweeps */
+int mg_coarse_solve_ex(mg_handle h, int level, int arr_x, int arr_rhs, int smoother, int maxit,
+                       double tol, int fixed, mg_cycle_stats *st);
 
 /* SawtoothMGIteration::apply_iteration_to_vec multigrid.hpp:126-145 (or the V-cycle
  * extension, per desc.cycle) applied to the solution array U of level 0 */

@@ -1,0 +1,472 @@
+// multigrid_hip.hpp -- C++ host mirror of the reference GeometricMultigrid API
+// (namespace MultiGrid: SquareDomain, PoissonMatrix, DataVector, Jacobi_iteration,
+// Gauss_Seidel_iteration, Residual, Solver, InterpolationClass, SawtoothMGIteration),
+// implemented on top of the C-ABI of mg_hip.h (libmg_hip.so, HIP kernels for gfx950).
+//
+// Same class names, constructor arguments, `apply_iteration_to_vec(std::vector<double>&)`
+// and `x * Op` chaining as the reference (paths relative to
+// /root/reference/GeometricMultigrid/: include/domain.hpp, include/linear_system.hpp,
+// include/solvers.hpp, include/multigrid.hpp), so the reference's main.cpp compiles
+// against this header unchanged apart from the include line.  Host std::vectors stay the
+// source of truth exactly as in the reference: each operator application moves its level's
+// entries to HBM, runs the HIP kernels and moves them back.  That is the compatibility
+// path; whole solves should use DeviceSolve (below) / mg_solve, which keep every array
+// resident in HBM.  There is no CPU fallback: constructing an operator without a GPU throws.
+//
+// Header-only, C++17, links against libmg_hip.so only.
+#ifndef MULTIGRID_HIP_HPP
+#define MULTIGRID_HIP_HPP
+
+#include <array>
+#include <cmath>
+#include <cstddef>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "mg_hip.h"
+
+#ifndef TOL
+#define TOL 1e-11  // include/solvers.hpp:5
+#endif
+
+namespace MultiGrid {
+
+struct HipError : std::runtime_error {
+    explicit HipError(int code) : std::runtime_error(std::string("libmg_hip: ") + mg_last_error()), status(code) {}
+    int status;
+};
+inline void mg_check(int rc) { if (rc != MG_OK) throw HipError(rc); }
+
+// ------------------------------------------------------------------ include/domain.hpp
+class Domain {
+public:
+    virtual ~Domain() = default;
+    virtual std::tuple<double, double> coord(const size_t i, const size_t j) const = 0;
+    virtual std::tuple<size_t, size_t> meshIdx(size_t l) const = 0;
+    virtual std::tuple<double, double> operator[](const size_t i) const = 0;
+    virtual bool isOnBoundary(const size_t l) const = 0;
+    virtual std::array<size_t, 5> inRowConnections_a(const size_t l) = 0;
+    virtual size_t mask(const size_t l) const = 0;
+    virtual size_t getWidth() const = 0;
+    virtual size_t numBoundaryNodes() const = 0;
+    virtual size_t numConnections() const = 0;
+    virtual size_t N() const = 0;
+    virtual double h() const = 0;
+    virtual size_t getStep() const = 0;
+    // additions needed to describe the hierarchy to the device library
+    virtual size_t fineSize() const = 0;
+    virtual double length() const = 0;
+    virtual size_t level() const = 0;
+};
+
+class SquareDomain : public Domain {
+public:
+    // domain.cpp:4-13 : width halves (rounding up) and step doubles per level
+    SquareDomain(const size_t size, const double length, const size_t level)
+        : m_size(size), m_step(1), m_level(level), m_width(size), m_length(length),
+          m_h(length / static_cast<double>(size - 1))
+    {
+        for (size_t i = 0; i < level; i++) { m_width = (m_width + 1) / 2; m_step *= 2; }
+    }
+    SquareDomain(const SquareDomain &dom, const size_t level) : SquareDomain(dom.m_size, dom.m_length, level) {}
+
+    std::tuple<size_t, size_t> meshIdx(size_t l) const override { return {l / m_size, l % m_size}; }
+    // row 0 is y = length; x runs along columns (domain.hpp:68)
+    std::tuple<double, double> coord(const size_t i, const size_t j) const override { return {j * m_h, m_length - i * m_h}; }
+    std::tuple<double, double> operator[](const size_t l) const override { auto [i, j] = meshIdx(mask(l)); return coord(i, j); }
+    bool isOnBoundary(const size_t l) const override
+    {
+        auto [i, j] = meshIdx(l);
+        return i == 0 || j == 0 || i == m_size - 1 || j == m_size - 1;
+    }
+    std::array<size_t, 5> inRowConnections_a(const size_t l) override { return {l - m_width, l - 1, l, l + 1, l + m_width}; }
+    size_t mask(const size_t l) const override { return m_step * (l / m_width) * m_size + m_step * (l % m_width); }
+    size_t getWidth() const override { return m_width; }
+    size_t numBoundaryNodes() const override { return m_width * 4 - 4; }
+    size_t numConnections() const override { return 4 * (m_width * m_width - numBoundaryNodes()); }
+    size_t N() const override { return m_width * m_width; }
+    double h() const override { return m_h * m_step; }
+    size_t getStep() const override { return m_step; }
+    size_t fineSize() const override { return m_size; }
+    double length() const override { return m_length; }
+    size_t level() const override { return m_level; }
+
+private:
+    size_t m_size, m_step, m_level, m_width;
+    double m_length, m_h;
+};
+
+// ------------------------------------------------------------ include/linear_system.hpp
+template <typename T>
+class PoissonMatrix {
+public:
+    PoissonMatrix(Domain &domain, const T const_alfa)
+        : m_domain(&domain), m_size(domain.N()), m_alpha(const_alfa), k(domain.h() * domain.h()) {}
+    // matrix-free coefficients (linear_system.hpp:21-42): identity rows on the boundary,
+    // 4*alpha/h^2 on the diagonal, -alpha/h^2 for the four neighbours
+    T coeffRef(const size_t i, const size_t j)
+    {
+        if (m_domain->isOnBoundary(m_domain->mask(i))) return (j == i) ? 1. : 0.;
+        if (j == i) return 4. * m_alpha / k;
+        size_t w = m_domain->getWidth();
+        size_t ri = i / w, ci = i % w, rj = j / w, cj = j % w;
+        size_t dr = ri > rj ? ri - rj : rj - ri, dc = ci > cj ? ci - cj : cj - ci;
+        // the reference tests "row distance == step OR column distance == step" (:37-38)
+        return (dr == 1 || dc == 1) ? -m_alpha / k : 0.;
+    }
+    const std::array<size_t, 5> nonZerosInRow_a(const size_t row) { return m_domain->inRowConnections_a(row); }
+    size_t nonZeros() { return m_size + m_domain->numConnections(); }
+    size_t mask(const size_t l) { return m_domain->mask(l); }
+    size_t getWidth() { return m_domain->getWidth(); }
+    bool isOnBoundary(const size_t l) { return m_domain->isOnBoundary(l); }
+    size_t rows() { return m_size; }
+    size_t cols() { return m_size; }
+    Domain &domain() { return *m_domain; }
+    T alpha() const { return m_alpha; }
+
+private:
+    Domain *m_domain;
+    size_t m_size;
+    T m_alpha;
+    double k;
+};
+
+template <typename T>
+class DataVector {
+public:
+    // b = g on boundary nodes, f inside (linear_system.hpp:85-92)
+    DataVector(Domain &domain, const std::function<T(double, double)> &f, const std::function<T(double, double)> &g)
+    {
+        m_vec.reserve(domain.N());
+        for (size_t i = 0; i < domain.N(); i++) {
+            auto [x, y] = domain[i];
+            m_vec.push_back(domain.isOnBoundary(i) ? g(x, y) : f(x, y));
+        }
+    }
+    const T &operator[](const size_t i) const { return m_vec[i]; }
+    size_t size() const { return m_vec.size(); }
+    const T *data() const { return m_vec.data(); }
+
+private:
+    std::vector<T> m_vec;
+};
+
+// ------------------------------------------------------------------ device plumbing
+namespace detail {
+
+// One HBM-resident hierarchy deep enough to hold `levels` grids of the given problem.
+class Hierarchy {
+public:
+    Hierarchy(size_t fine_n, double length, double alpha, int levels, int smoother)
+    {
+        mg_desc d;
+        mg_desc_reference_defaults(&d, static_cast<int>(fine_n), levels, length, alpha, smoother);
+        mg_check(mg_create(&d, -1, &h_));
+        n0_ = fine_n;
+        levels_ = levels;
+    }
+    ~Hierarchy() { mg_destroy(h_); }
+    Hierarchy(const Hierarchy &) = delete;
+    Hierarchy &operator=(const Hierarchy &) = delete;
+    mg_handle get() const { return h_; }
+    size_t fine_n() const { return n0_; }
+
+    // level entries of a fine-size host vector (addressed like Domain::mask) <-> device array
+    template <class Vector>
+    void upload(int arr, int level, const Vector &v)
+    {
+        size_t step = size_t(1) << level, w = (n0_ - 1) / step + 1;
+        buf_.resize(w * w);
+        for (size_t r = 0; r < w; r++)
+            for (size_t c = 0; c < w; c++) buf_[r * w + c] = v[step * r * n0_ + step * c];
+        mg_check(mg_set_array(h_, arr, level, buf_.data()));
+    }
+    void download(int arr, int level, std::vector<double> &v)
+    {
+        size_t step = size_t(1) << level, w = (n0_ - 1) / step + 1;
+        buf_.resize(w * w);
+        mg_check(mg_get_array(h_, arr, level, buf_.data()));
+        for (size_t r = 0; r < w; r++)
+            for (size_t c = 0; c < w; c++) v[step * r * n0_ + step * c] = buf_[r * w + c];
+    }
+
+private:
+    mg_handle h_ = nullptr;
+    size_t n0_ = 0;
+    int levels_ = 0;
+    std::vector<double> buf_;
+};
+
+inline std::unique_ptr<Hierarchy> hierarchy_for(PoissonMatrix<double> &A, int smoother)
+{
+    Domain &d = A.domain();
+    return std::make_unique<Hierarchy>(d.fineSize(), d.length(), A.alpha(), static_cast<int>(d.level()) + 1, smoother);
+}
+
+}  // namespace detail
+
+// ------------------------------------------------------------------ include/solvers.hpp
+template <class Vector>
+class SmootherClass {
+public:
+    virtual ~SmootherClass() = default;
+    virtual void apply_iteration_to_vec(std::vector<double> &sol) = 0;
+    inline friend std::vector<double> &operator*(std::vector<double> &x_k, SmootherClass &B)
+    {
+        B.apply_iteration_to_vec(x_k);
+        return x_k;
+    }
+    // Hooks used by Solver (below) to keep the whole iterate-to-tolerance loop on the device.
+    // A user-defined smoother keeps the defaults and is iterated through the generic loop.
+    virtual int device_smoother() const { return -1; }
+    virtual int level() const { return -1; }
+    virtual detail::Hierarchy *hierarchy() { return nullptr; }
+    virtual void upload_rhs() {}
+};
+
+namespace detail {
+template <class Vector, int SMOOTHER>
+class DeviceSmoother : public SmootherClass<Vector> {
+public:
+    DeviceSmoother(PoissonMatrix<double> &A, Vector &f)
+        : m_A(A), b(f), H(hierarchy_for(A, SMOOTHER)), lvl(static_cast<int>(A.domain().level())) {}
+    void apply_iteration_to_vec(std::vector<double> &sol) override
+    {
+        H->upload(MG_ARR_RHS, lvl, b);
+        H->upload(MG_ARR_E, lvl, sol);
+        mg_check(mg_smooth(H->get(), lvl, SMOOTHER, 1, MG_ARR_E, MG_ARR_RHS));
+        H->download(MG_ARR_E, lvl, sol);
+    }
+    int device_smoother() const override { return SMOOTHER; }
+    int level() const override { return lvl; }
+    Hierarchy *hierarchy() override { return H.get(); }
+    void upload_rhs() override { H->upload(MG_ARR_RHS, lvl, b); }
+
+private:
+    PoissonMatrix<double> &m_A;
+    Vector &b;
+    std::unique_ptr<Hierarchy> H;
+    int lvl;
+};
+}  // namespace detail
+
+// solvers.hpp:24-49 (lexicographic, in place) -> wavefront HIP kernel, bit-identical
+template <class Vector>
+class Gauss_Seidel_iteration : public detail::DeviceSmoother<Vector, MG_SMOOTH_GS_LEX> {
+public:
+    using detail::DeviceSmoother<Vector, MG_SMOOTH_GS_LEX>::DeviceSmoother;
+};
+// solvers.hpp:53-84 (the reference swaps `sol` with its `temp`; here `sol` keeps its buffer
+// and only the level's entries change -- the entries the reference guarantees)
+template <class Vector>
+class Jacobi_iteration : public detail::DeviceSmoother<Vector, MG_SMOOTH_JACOBI> {
+public:
+    using detail::DeviceSmoother<Vector, MG_SMOOTH_JACOBI>::DeviceSmoother;
+};
+
+// solvers.hpp:219-308
+template <class Vector>
+class Residual {
+public:
+    Residual(PoissonMatrix<double> &A, Vector &f)
+        : m_A(A), b(f), m_res(nullptr), H(detail::hierarchy_for(A, MG_SMOOTH_JACOBI)),
+          lvl(static_cast<int>(A.domain().level()))
+    {
+        // the reference's 2-argument ctor sums over ALL fine entries (:230-235); callers
+        // refresh it before use (multigrid.hpp:128)
+        for (size_t i = 0; i < b.size(); i++) norm_of_b += b[i] * b[i];
+    }
+    Residual(PoissonMatrix<double> &A, Vector &f, std::vector<double> &res)
+        : m_A(A), b(f), m_res(&res), H(detail::hierarchy_for(A, MG_SMOOTH_JACOBI)),
+          lvl(static_cast<int>(A.domain().level()))
+    {
+        refresh_normalization_constant();
+    }
+    void refresh_normalization_constant()
+    {
+        H->upload(MG_ARR_RHS, lvl, b);
+        mg_check(mg_sumsq(H->get(), lvl, MG_ARR_RHS, &norm_of_b));
+    }
+    void apply_iteration_to_vec(std::vector<double> &sol)
+    {
+        H->upload(MG_ARR_RHS, lvl, b);
+        H->upload(MG_ARR_E, lvl, sol);
+        mg_check(mg_residual(H->get(), lvl, MG_ARR_E, MG_ARR_RHS, m_res ? MG_ARR_TMP : -1, &norm));
+        if (m_res) H->download(MG_ARR_TMP, lvl, *m_res);
+    }
+    friend std::vector<double> &operator*(std::vector<double> &x_k, Residual &B)
+    {
+        B.apply_iteration_to_vec(x_k);
+        return x_k;
+    }
+    double Norm() { return std::sqrt(norm / norm_of_b); }
+    PoissonMatrix<double> &matrix() { return m_A; }
+
+private:
+    PoissonMatrix<double> &m_A;
+    Vector &b;
+    std::vector<double> *m_res;
+    std::unique_ptr<detail::Hierarchy> H;
+    int lvl;
+    double norm_of_b = 0., norm = 0.;
+};
+
+// solvers.hpp:310-353 -- same observable behaviour, one persistent-workgroup launch
+template <class Vector>
+class Solver {
+public:
+    Solver(SmootherClass<Vector> &it, Residual<Vector> &res, size_t maxit, double tol, int step)
+        : m_it(it), m_res(res), m_maxit(maxit), m_tol(tol), m_step(step)
+    {
+        if (step != 1) throw std::invalid_argument("MultiGrid::Solver: only step == 1 (the reference's use) is supported");
+    }
+    void Solve(std::vector<double> &x_k)
+    {
+        if (m_it.device_smoother() < 0 || !m_it.hierarchy()) {
+            // user-defined smoother: iterate it operator by operator (solvers.hpp:324-342)
+            size_t counter = m_maxit;
+            iterations = 0;
+            x_k * m_res;
+            while (m_res.Norm() > m_tol) {
+                if (counter == 0) { flag = 1; return; }
+                x_k * m_it;
+                counter -= 1;
+                iterations++;
+                x_k * m_res;
+            }
+            flag = 0;
+            return;
+        }
+        detail::Hierarchy &H = *m_it.hierarchy();
+        const int lvl = m_it.level();
+        m_it.upload_rhs();
+        H.upload(MG_ARR_E, lvl, x_k);
+        mg_cycle_stats st{};
+        mg_check(mg_coarse_solve_ex(H.get(), lvl, MG_ARR_E, MG_ARR_RHS, m_it.device_smoother(),
+                                    static_cast<int>(m_maxit), m_tol, 0, &st));
+        H.download(MG_ARR_E, lvl, x_k);
+        flag = st.coarse_flag;
+        iterations = st.coarse_iters;
+        x_k * m_res;  // leaves the Residual object in the state the reference leaves it in
+    }
+    int Status() { return flag; }
+    int Iterations() const { return iterations; }  // extension: sweeps spent
+    friend std::vector<double> &operator*(std::vector<double> &x_k, Solver &B)
+    {
+        B.Solve(x_k);
+        return x_k;
+    }
+
+private:
+    SmootherClass<Vector> &m_it;
+    Residual<Vector> &m_res;
+    size_t m_maxit;
+    double m_tol;
+    int flag = 0, iterations = 0;
+    int m_step;
+};
+
+// ---------------------------------------------------------------- include/multigrid.hpp
+class InterpolationClass {
+public:
+    // (A_inf = coarse level, A_sup = fine level), multigrid.hpp:13
+    InterpolationClass(PoissonMatrix<double> &A_inf, PoissonMatrix<double> &A_sup)
+        : H(detail::hierarchy_for(A_inf, MG_SMOOTH_JACOBI)), coarse(static_cast<int>(A_inf.domain().level())),
+          fine(static_cast<int>(A_sup.domain().level()))
+    {
+        if (coarse != fine + 1) throw std::invalid_argument("InterpolationClass: levels must be adjacent");
+    }
+    void interpolate(std::vector<double> &vec)  // src/multigrid.cpp:3-27
+    {
+        H->upload(MG_ARR_E, coarse, vec);
+        mg_check(mg_prolong(H->get(), coarse, 0, MG_ARR_E, MG_ARR_E));
+        H->download(MG_ARR_E, fine, vec);
+    }
+    friend std::vector<double> &operator*(std::vector<double> &x_k, InterpolationClass &B)
+    {
+        B.interpolate(x_k);
+        return x_k;
+    }
+
+private:
+    std::unique_ptr<detail::Hierarchy> H;
+    int coarse, fine;
+};
+
+namespace detail {
+template <class S> struct smoother_id;
+template <class V> struct smoother_id<Gauss_Seidel_iteration<V>> { static constexpr int value = MG_SMOOTH_GS_LEX; };
+template <class V> struct smoother_id<Jacobi_iteration<V>> { static constexpr int value = MG_SMOOTH_JACOBI; };
+}  // namespace detail
+
+// multigrid.hpp:88-158. The whole cycle (residual, injection, persistent coarse solve,
+// prolongation + nu sweeps per level, correction) runs stream-ordered on the GPU.
+template <class Vector, class Smoother>
+class SawtoothMGIteration {
+public:
+    SawtoothMGIteration(std::vector<PoissonMatrix<double>> &matrices, Vector &knownVec)
+        : A_level(matrices), b(knownVec)
+    {
+        Domain &d = A_level.front().domain();
+        H = std::make_unique<detail::Hierarchy>(d.fineSize(), d.length(), A_level.front().alpha(),
+                                                static_cast<int>(A_level.size()), detail::smoother_id<Smoother>::value);
+    }
+    void apply_iteration_to_vec(std::vector<double> &sol)
+    {
+        H->upload(MG_ARR_RHS, 0, b);
+        H->upload(MG_ARR_U, 0, sol);
+        mg_cycle_stats st{};
+        mg_check(mg_cycle(H->get(), &st));
+        std::cout << "Achieved residual on coarse grid: " << st.coarse_relres << std::endl;  // multigrid.hpp:131
+        last = st;
+        H->download(MG_ARR_U, 0, sol);
+    }
+    friend std::vector<double> &operator*(std::vector<double> &x_k, SawtoothMGIteration &B)
+    {
+        B.apply_iteration_to_vec(x_k);
+        return x_k;
+    }
+    const mg_cycle_stats &last_stats() const { return last; }
+
+private:
+    std::vector<PoissonMatrix<double>> &A_level;
+    Vector &b;
+    std::unique_ptr<detail::Hierarchy> H;
+    mg_cycle_stats last{};
+};
+
+// ---------------------------------------------------------------------------------------
+// DeviceSolve: the outer loop of src/main.cpp:72-116 with every array resident in HBM
+// (what our `Multigrid` executable uses). hist[0] is the initial relative residual.
+struct SolveResult {
+    std::vector<double> hist;
+    std::vector<mg_cycle_stats> cycles;
+};
+inline SolveResult DeviceSolve(const mg_desc &desc, const double *b, std::vector<double> &u, double tol = TOL,
+                               int max_iter = 1000, bool echo_coarse = true)
+{
+    mg_handle h = nullptr;
+    mg_check(mg_create(&desc, -1, &h));
+    struct Guard { mg_handle h; ~Guard() { mg_destroy(h); } } guard{h};
+    mg_check(mg_set_rhs(h, b));
+    mg_check(mg_set_solution(h, u.data()));
+    SolveResult r;
+    r.hist.resize(static_cast<size_t>(max_iter) + 1);
+    r.cycles.resize(static_cast<size_t>(max_iter));
+    int nh = 0;
+    mg_check(mg_solve(h, tol, max_iter, r.hist.data(), max_iter + 1, &nh, r.cycles.data()));
+    r.hist.resize(static_cast<size_t>(nh));
+    r.cycles.resize(static_cast<size_t>(nh - 1));
+    if (echo_coarse)
+        for (const auto &c : r.cycles) std::cout << "Achieved residual on coarse grid: " << c.coarse_relres << std::endl;
+    mg_check(mg_get_solution(h, u.data()));
+    return r;
+}
+
+}  // namespace MultiGrid
+#endif  // MULTIGRID_HIP_HPP

@@ -51,5 +51,35 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+CLI_PATH = os.path.join(LIB_DIR, "Multigrid")
+HOST = os.path.join(_HERE, "host")
+
+
+def build_cli(force: bool = False) -> str:
+    """The `Multigrid` executable (host C++ only; g++), linked against the in-tree library.
+    The CMake target of the same name (CMakeLists.txt) builds the same sources."""
+    build()
+    srcs = [os.path.join(HOST, "main.cpp"), os.path.join(HOST, "utilities.cpp")]
+    deps = srcs + [os.path.join(HOST, "utilities.hpp"), os.path.join(ROOT, "include", "multigrid_hip.hpp"), LIB_PATH]
+    if force or not os.path.exists(CLI_PATH) or any(os.path.getmtime(f) > os.path.getmtime(CLI_PATH) for f in deps):
+        subprocess.run(["g++", "-std=c++20", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, *srcs,
+                        "-L" + LIB_DIR, "-lmg_hip", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib",
+                        "-o", CLI_PATH], check=True)
+    return CLI_PATH
+
+
+def build_mirror_harness(out_path: str) -> str:
+    """Compiles oracle/ref_harness.cpp -- written against the REFERENCE classes -- unchanged
+    against include/multigrid_hip.hpp (tests/cpp/shim/allIncludes.hpp): the drop-in check."""
+    build()
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    subprocess.run(["g++", "-std=c++20", "-O2", "-w", "-I" + os.path.join(ROOT, "tests", "cpp", "shim"),
+                    "-I" + os.path.join(ROOT, "include"), "-I" + HOST,
+                    os.path.join(ROOT, "oracle", "ref_harness.cpp"), os.path.join(HOST, "utilities.cpp"),
+                    "-L" + LIB_DIR, "-lmg_hip", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib",
+                    "-o", out_path], check=True)
+    return out_path
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -70,7 +70,7 @@ EXPORTS = [
     "mg_last_error", "mg_device_count", "mg_create", "mg_destroy", "mg_level_n",
     "mg_level_coefficients", "mg_set_rhs", "mg_set_solution", "mg_get_solution", "mg_set_array",
     "mg_get_array", "mg_zero_array", "mg_smooth", "mg_residual", "mg_sumsq", "mg_restrict",
-    "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_cycle", "mg_cycle_async", "mg_solve",
+    "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_coarse_solve_ex", "mg_cycle", "mg_cycle_async", "mg_solve",
     "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_device_bytes", "mg_comm_unique_id",
     "mg_create_distributed", "mg_plan_slab",
 ]
@@ -109,6 +109,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.mg_prolong.argtypes = [vp, i, i, i, i]
     L.mg_correct.argtypes = [vp, i, i]
     L.mg_coarse_solve.argtypes = [vp, i, i, i, C.POINTER(MgCycleStats)]
+    L.mg_coarse_solve_ex.argtypes = [vp, i, i, i, i, i, C.c_double, i, C.POINTER(MgCycleStats)]
     L.mg_cycle.argtypes = [vp, C.POINTER(MgCycleStats)]
     L.mg_cycle_async.argtypes = [vp, i]
     L.mg_solve.argtypes = [vp, C.c_double, i, dp, i, C.POINTER(i), C.POINTER(MgCycleStats)]

@@ -132,6 +132,12 @@ int mg_coarse_solve(mg_handle h, int level, int arr_x, int arr_rhs, mg_cycle_sta
     MG_H(h);
     return guarded([&] { return h->impl->coarse_solve(level, arr_x, arr_rhs, st); });
 }
+int mg_coarse_solve_ex(mg_handle h, int level, int arr_x, int arr_rhs, int smoother, int maxit,
+                       double tol, int fixed, mg_cycle_stats *st)
+{
+    MG_H(h);
+    return guarded([&] { return h->impl->coarse_solve_ex(level, arr_x, arr_rhs, smoother, maxit, tol, fixed, st); });
+}
 int mg_cycle(mg_handle h, mg_cycle_stats *st) { MG_H(h); return guarded([&] { return h->impl->cycle(st); }); }
 int mg_cycle_async(mg_handle h, int count) { MG_H(h); return guarded([&] { return h->impl->cycle_async(count); }); }
 int mg_solve(mg_handle h, double tol, int maxit, double *hist, int hist_cap, int *n_hist,

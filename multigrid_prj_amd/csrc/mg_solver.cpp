@@ -392,23 +392,40 @@ int Solver::correct(int arr_u, int arr_e)
 }
 
 template <typename T>
-int Solver::coarse_t(int level, int ax, int ar)
+int Solver::coarse_ex_t(int level, int ax, int ar, int smoother, int maxit, double tol, int fixed)
 {
     Level &L = lv_[level];
-    launch_coarse_solve<T>(stream_, L.g, coef_of<T>(L), (T)d_.omega, d_.smoother, ptr<T>(ax, level),
-                           ptr<T>(MG_ARR_TMP, level), ptr<T>(ar, level), d_.coarse_maxit,
-                           d_.coarse_tol, d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0, d_coarse_);
+    launch_coarse_solve<T>(stream_, L.g, coef_of<T>(L), (T)d_.omega, smoother, ptr<T>(ax, level),
+                           ptr<T>(MG_ARR_TMP, level), ptr<T>(ar, level), maxit, tol, fixed, d_coarse_);
     MG_HIP(hipGetLastError());
     return MG_OK;
 }
 
+template <typename T>
+int Solver::coarse_t(int level, int ax, int ar)
+{
+    return coarse_ex_t<T>(level, ax, ar, d_.smoother, d_.coarse_maxit, d_.coarse_tol,
+                          d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0);
+}
+
 int Solver::coarse_solve(int level, int arr_x, int arr_rhs, mg_cycle_stats *st)
 {
+    return coarse_solve_ex(level, arr_x, arr_rhs, d_.smoother, d_.coarse_maxit, d_.coarse_tol,
+                           d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0, st);
+}
+
+int Solver::coarse_solve_ex(int level, int arr_x, int arr_rhs, int smoother, int maxit, double tol, int fixed,
+                            mg_cycle_stats *st)
+{
     if (!check_arr(arr_x, level, "mg_coarse_solve") || !check_arr(arr_rhs, level, "mg_coarse_solve") ||
-        arr_x == MG_ARR_TMP || arr_rhs == MG_ARR_TMP || arr_x == arr_rhs)
+        arr_x == MG_ARR_TMP || arr_rhs == MG_ARR_TMP || arr_x == arr_rhs || maxit < 0 ||
+        smoother < MG_SMOOTH_GS_LEX || smoother > MG_SMOOTH_RBGS) {
+        set_last_error("mg_coarse_solve: bad array / smoother / maxit");
         return MG_ERR_BAD_ARG;
+    }
     MG_HIP(hipSetDevice(device_));
-    int rc = d_.dtype == MG_F64 ? coarse_t<double>(level, arr_x, arr_rhs) : coarse_t<float>(level, arr_x, arr_rhs);
+    int rc = d_.dtype == MG_F64 ? coarse_ex_t<double>(level, arr_x, arr_rhs, smoother, maxit, tol, fixed)
+                                : coarse_ex_t<float>(level, arr_x, arr_rhs, smoother, maxit, tol, fixed);
     if (rc) return rc;
     MG_HIP(hipMemcpyAsync(h_coarse_, d_coarse_, sizeof(CoarseOut), hipMemcpyDeviceToHost, stream_));
     MG_HIP(hipStreamSynchronize(stream_));

@@ -53,6 +53,8 @@ public:
     int prolong(int coarse_level, int add, int arr_src, int arr_dst);
     int correct(int arr_u, int arr_e);
     int coarse_solve(int level, int arr_x, int arr_rhs, mg_cycle_stats *st);
+    int coarse_solve_ex(int level, int arr_x, int arr_rhs, int smoother, int maxit, double tol, int fixed,
+                        mg_cycle_stats *st);
     int cycle(mg_cycle_stats *st);
     int cycle_async(int count);
     int solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist,
@@ -77,6 +79,7 @@ private:
     template <typename T> int prolong_t(int cl, int add, int as, int ad);
     template <typename T> int correct_t(int au, int ae);
     template <typename T> int coarse_t(int level, int ax, int ar);
+    template <typename T> int coarse_ex_t(int level, int ax, int ar, int smoother, int maxit, double tol, int fixed);
     template <typename T> int cycle_enqueue_t();
     template <typename T> int vcycle_rec_t(int l);
     int cycle_enqueue();

@@ -1,0 +1,104 @@
+// main.cpp -- the `Multigrid` executable: same command line, stdout protocol and result
+// files (MGGS4.txt, x.mtx) as /root/reference/GeometricMultigrid/src/main.cpp, with the
+// whole solve resident on the GPU (MultiGrid::DeviceSolve -> mg_solve in libmg_hip.so).
+#include <chrono>
+#include <cmath>
+#include <iostream>
+
+#include "multigrid_hip.hpp"
+#include "utilities.hpp"
+
+int main(int argc, char **argv)
+{
+    Utils::Options opt;
+    Utils::parse_command_line(argc, argv, opt);
+    std::function<double(const double, const double)> f, g;
+    Utils::init_test_functions(f, g, opt.test);
+
+    auto start = std::chrono::high_resolution_clock::now();
+
+    mg_desc d;
+    // -smt 2 ("BiCGSTAB") runs the Jacobi cycle in the reference too (main.cpp:103-106)
+    const int smoother = opt.rbgs ? MG_SMOOTH_RBGS : (opt.smoother == Gauss_Siedel ? MG_SMOOTH_GS_LEX : MG_SMOOTH_JACOBI);
+    mg_desc_reference_defaults(&d, static_cast<int>(opt.N), opt.level, opt.width, opt.alpha, smoother);
+    d.dim = opt.dim;
+    d.omega = opt.omega;
+    if (opt.fp32) d.dtype = MG_F32;
+    if (opt.vcycle) {
+        d.cycle = MG_CYCLE_V;
+        d.nu_pre = opt.nu1;
+        d.nu_post = opt.nu2 >= 0 ? opt.nu2 : 2;
+        d.outer_pre_gs = 0;
+    } else if (opt.nu2 >= 0) {
+        d.nu_post = opt.nu2;
+    }
+    if (opt.full_weighting) d.restriction = MG_RESTRICT_FULLW;
+    if (opt.coarse_fixed >= 0) { d.coarse_mode = MG_COARSE_FIXED; d.coarse_maxit = opt.coarse_fixed; }
+    if (opt.dim == 3) d.outer_pre_gs = 0;
+
+    // right-hand side: g on the boundary, f inside (DataVector)
+    std::vector<double> b;
+    size_t n = opt.N, total = (opt.dim == 3) ? n * n * n : n * n;
+    if (opt.dim == 2) {
+        MultiGrid::SquareDomain fine(opt.N, opt.width, 0);
+        MultiGrid::DataVector<double> fvec(fine, f, g);
+        b.assign(fvec.data(), fvec.data() + fvec.size());
+    } else {
+        // 3-D extension: the 2-D (f, g) pair extruded along z, g on all six faces
+        const double h = opt.width / static_cast<double>(n - 1);
+        b.resize(total);
+        for (size_t k = 0; k < n; k++)
+            for (size_t j = 0; j < n; j++)
+                for (size_t i = 0; i < n; i++) {
+                    bool bnd = i == 0 || j == 0 || k == 0 || i == n - 1 || j == n - 1 || k == n - 1;
+                    double x = i * h, y = opt.width - j * h;
+                    b[(k * n + j) * n + i] = bnd ? g(x, y) : f(x, y);
+                }
+    }
+    std::vector<double> u(total, 0.);
+
+    auto end = std::chrono::high_resolution_clock::now();
+    std::chrono::duration<double> init_time = end - start;
+    std::cout << "Initialization time: " << init_time.count() << " seconds" << std::endl;
+    start = std::chrono::high_resolution_clock::now();
+
+    switch (opt.smoother) {
+    case Gauss_Siedel: std::cout << "GS iters" << std::endl; break;
+    case Jacobi: std::cout << "Jacobi iters" << std::endl; break;
+    default: std::cout << "BiCGSTAB iters" << std::endl; break;
+    }
+    const int MaxIter = opt.maxit;
+    MultiGrid::SolveResult res;
+    try {
+        if (opt.fp32) {
+            std::vector<float> bf(b.begin(), b.end()), uf(total, 0.f);
+            mg_handle h = nullptr;
+            MultiGrid::mg_check(mg_create(&d, -1, &h));
+            MultiGrid::mg_check(mg_set_rhs(h, bf.data()));
+            res.hist.resize(MaxIter + 1);
+            res.cycles.resize(MaxIter);
+            int nh = 0;
+            MultiGrid::mg_check(mg_solve(h, TOL, MaxIter, res.hist.data(), MaxIter + 1, &nh, res.cycles.data()));
+            res.hist.resize(nh);
+            MultiGrid::mg_check(mg_get_solution(h, uf.data()));
+            mg_destroy(h);
+            u.assign(uf.begin(), uf.end());
+        } else {
+            res = MultiGrid::DeviceSolve(d, b.data(), u, TOL, MaxIter);
+        }
+    } catch (const MultiGrid::HipError &e) {
+        // the reference does not validate n against levels and reads out of range; we stop
+        std::cout << "Error: " << e.what() << std::endl;
+        return 1;
+    }
+
+    end = std::chrono::high_resolution_clock::now();
+    std::chrono::duration<double> solve_time = end - start;
+    std::cout << "||Solving elapsed time: " << solve_time.count() << " sec<br>" << std::endl;
+    std::cout << "Tol: " << TOL << "<br>" << std::endl;
+    std::cout << "Max iter: " << MaxIter << "<br>" << std::endl;
+
+    Utils::saveVectorOnFile(res.hist, "MGGS4.txt");
+    Utils::saveVectorOnFile(u, "x.mtx");
+    return 0;
+}

@@ -1,0 +1,57 @@
+// utilities.hpp -- CLI, test-function table and result writers of the `Multigrid` executable.
+// Same flags, defaults, messages and file formats as the reference driver
+// (/root/reference/GeometricMultigrid/include/utilities.hpp, src/utilities.cpp), re-written.
+#ifndef MG_HOST_UTILITIES_HPP
+#define MG_HOST_UTILITIES_HPP
+
+#include <fstream>
+#include <functional>
+#include <string>
+#include <vector>
+
+enum SMOOTHERS { Gauss_Siedel, Jacobi, BiCGSTAB, SMOOTHERS_END };  // utilities.hpp:9-14
+
+#define DEFAULT_N 200  // the reference's default; refused here because 199 is odd (see Options)
+#define DEFAULT_ALPHA 10.0
+#define DEFAULT_WIDTH 10.0
+#define DEFAULT_LEVEL 2
+#define DEFAULT_TEST 1
+#define DEFAULT_METHOD Gauss_Siedel
+
+namespace Utils {
+
+struct Options {
+    // reference flags -n -a -w -ml -test -smt
+    size_t N = DEFAULT_N;
+    double alpha = DEFAULT_ALPHA;
+    double width = DEFAULT_WIDTH;
+    int level = DEFAULT_LEVEL;
+    int test = DEFAULT_TEST;
+    SMOOTHERS smoother = DEFAULT_METHOD;
+    // extensions (absent from the reference): -dim 3, -cycle v, -omega, -nu1, -nu2, -rbgs,
+    // -fw, -coarse_fixed K, -fp32, -maxit
+    int dim = 2;
+    bool vcycle = false, rbgs = false, full_weighting = false, fp32 = false;
+    double omega = 1.0;
+    int nu1 = 2, nu2 = -1, coarse_fixed = -1, maxit = 1000;
+};
+
+// Parses argv like the reference's Initialization_for_N (same echo lines, same `Error: …`
+// messages on stdout, exit(1) on error or --help).
+void parse_command_line(int argc, char **argv, Options &opt);
+
+// (f, g) pairs of the reference table; an index outside 0..2 selects pair 0 with a warning.
+void init_test_functions(std::function<double(const double, const double)> &f,
+                         std::function<double(const double, const double)> &g, int i);
+
+// first line = element count, then one value per line, default ostream precision
+template <class Vector>
+void saveVectorOnFile(const Vector &f, const std::string &fileName)
+{
+    std::ofstream file(fileName, std::ofstream::trunc);
+    file << f.size() << std::endl;
+    for (size_t i = 0; i < f.size(); i++) file << f[i] << std::endl;
+}
+
+}  // namespace Utils
+#endif
