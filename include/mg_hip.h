@@ -135,6 +135,25 @@ int mg_comm_unique_id(void *id128);
 /* like mg_create, for rank `rank` of `nranks` (one process per GPU) */
 int mg_create_distributed(const mg_desc *desc, int device, int rank, int nranks,
                           const void *id128, mg_handle *out);
+/* The same distributed solver with the exchanges delegated to the HOST (test transport:
+ * the library stages halo planes through pinned host buffers and calls back; tests wire the
+ * callbacks to torch.distributed/gloo so two processes sharing one GPU can exercise the
+ * whole multi-rank path). `batch` must post every op of the list concurrently and return
+ * when all have completed; `allreduce_sum` sums n doubles over all ranks in place. Both
+ * return 0 on success. */
+typedef struct mg_p2p_op {
+    int32_t peer;     /* rank to send to / receive from */
+    int32_t is_send;  /* 1 = send, 0 = receive          */
+    void   *buf;      /* host buffer                    */
+    size_t  bytes;
+} mg_p2p_op;
+typedef struct mg_host_comm {
+    void *ctx;
+    int (*batch)(void *ctx, const mg_p2p_op *ops, int nops);
+    int (*allreduce_sum)(void *ctx, double *vals, int n);
+} mg_host_comm;
+int mg_create_distributed_hostcomm(const mg_desc *desc, int device, int rank, int nranks,
+                                   const mg_host_comm *comm, mg_handle *out);
 /* host-only partition plan (no GPU needed): z-planes [z0, z0+nz) of level l owned by
  * rank r, and the first level that is agglomerated on rank 0 */
 int mg_plan_slab(const mg_desc *desc, int nranks, int rank, int level, int *z0, int *nz,

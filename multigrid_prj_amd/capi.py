@@ -65,6 +65,18 @@ def make_desc(dim=2, n=17, levels=2, dtype=MG_F64, length=10.0, alpha=1.0,
     return d
 
 
+class MgP2POp(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("is_send", C.c_int32), ("buf", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(MgP2POp), C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
+
+class MgHostComm(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("batch", BATCH_FN), ("allreduce_sum", ALLREDUCE_FN)]
+
+
 # every symbol include/mg_hip.h declares (tests check the library exports them all)
 EXPORTS = [
     "mg_last_error", "mg_device_count", "mg_create", "mg_destroy", "mg_level_n",
@@ -72,7 +84,7 @@ EXPORTS = [
     "mg_get_array", "mg_zero_array", "mg_smooth", "mg_residual", "mg_sumsq", "mg_restrict",
     "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_coarse_solve_ex", "mg_cycle", "mg_cycle_async", "mg_solve",
     "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_device_bytes", "mg_comm_unique_id",
-    "mg_create_distributed", "mg_plan_slab",
+    "mg_create_distributed", "mg_create_distributed_hostcomm", "mg_plan_slab",
 ]
 
 _lib = None
@@ -121,6 +133,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.mg_device_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.mg_comm_unique_id.argtypes = [vp]
     L.mg_create_distributed.argtypes = [C.POINTER(MgDesc), i, i, i, vp, C.POINTER(vp)]
+    L.mg_create_distributed_hostcomm.argtypes = [C.POINTER(MgDesc), i, i, i, C.POINTER(MgHostComm), C.POINTER(vp)]
     L.mg_plan_slab.argtypes = [C.POINTER(MgDesc), i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     _lib = L
     return L
@@ -154,12 +167,17 @@ class Solver:
     """One GPU-resident hierarchy. Mirrors the operator vocabulary of the reference
     (`x * smoother`, `x * RES`, interpolate, Solve, SawtoothMGIteration, main loop)."""
 
-    def __init__(self, desc: MgDesc, device: int = -1, rank: int = 0, nranks: int = 1, comm_id: bytes | None = None):
+    def __init__(self, desc: MgDesc, device: int = -1, rank: int = 0, nranks: int = 1, comm_id: bytes | None = None,
+                 host_comm: "MgHostComm | None" = None):
         self.lib = load()
         self.d = desc
         self.np = np.float64 if desc.dtype == MG_F64 else np.float32
         self.h = C.c_void_p()
-        if nranks > 1:
+        self.rank, self.nranks = rank, nranks
+        self._host_comm = host_comm  # keep the callbacks alive
+        if nranks > 1 and host_comm is not None:
+            _check(self.lib.mg_create_distributed_hostcomm(C.byref(desc), device, rank, nranks, C.byref(host_comm), C.byref(self.h)))
+        elif nranks > 1:
             buf = C.create_string_buffer(comm_id, MG_COMM_ID_BYTES)
             _check(self.lib.mg_create_distributed(C.byref(desc), device, rank, nranks, buf, C.byref(self.h)))
         else:
@@ -187,7 +205,12 @@ class Solver:
         n = C.c_int(0); _check(self.lib.mg_level_n(self.h, level, C.byref(n))); return n.value
 
     def level_shape(self, level: int):
-        return (self.level_n(level),) * self.d.dim
+        """Host shape of this rank's part of a level (the local z-slab when distributed)."""
+        n = self.level_n(level)
+        if self.nranks > 1:
+            z0, nz, fg = plan_slab(self.d, self.nranks, self.rank, level)
+            return (nz, n, n)
+        return (n,) * self.d.dim
 
     def level_coefficients(self, level: int):
         out = (C.c_double * 4)(); _check(self.lib.mg_level_coefficients(self.h, level, out)); return tuple(out)

@@ -177,18 +177,59 @@ int mg_plan_slab(const mg_desc *desc, int nranks, int rank, int level, int *z0, 
 
 int mg_comm_unique_id(void *id128)
 {
-    (void)id128;
-    mg::set_last_error("mg_comm_unique_id: multi-GPU path not built yet");
-    return MG_ERR_COMM;
+    if (!id128) return bad("mg_comm_unique_id: null argument");
+    std::string why;
+    int rc = mg::rccl_unique_id(id128, &why);
+    if (rc) mg::set_last_error("mg_comm_unique_id: " + why);
+    return rc;
+}
+
+static int create_with_comm(const mg_desc *desc, int device, int rank, int nranks, mg::Comm *comm, mg_handle *out)
+{
+    (void)rank; (void)nranks;
+    mg::Solver *s = new mg::Solver(*desc, device, comm);  // owns comm
+    int rc = s->init();
+    if (rc) { delete s; return rc; }
+    *out = new mg_solver{s};
+    return MG_OK;
 }
 
 int mg_create_distributed(const mg_desc *desc, int device, int rank, int nranks, const void *id128,
                           mg_handle *out)
 {
-    (void)id128;
-    if (nranks == 1 && rank == 0) return mg_create(desc, device, out);
-    mg::set_last_error("mg_create_distributed: multi-GPU path not built yet");
-    return MG_ERR_COMM;
+    return guarded([&]() -> int {
+        if (!out) return bad("mg_create_distributed: null output handle");
+        *out = nullptr;
+        if (nranks == 1 && rank == 0) return mg_create(desc, device, out);
+        std::string why;
+        int rc = mg::validate_desc(desc, &why);
+        if (rc) { mg::set_last_error("mg_create_distributed: " + why); return rc; }
+        mg::SlabPlan p;
+        rc = mg::plan_slab(*desc, nranks, rank, 0, &p, &why);
+        if (rc) { mg::set_last_error("mg_create_distributed: " + why); return rc; }
+        if (device >= 0 && hipSetDevice(device) != hipSuccess) return bad("mg_create_distributed: bad device");
+        mg::Comm *c = mg::make_rccl_comm(rank, nranks, id128, &why);
+        if (!c) { mg::set_last_error("mg_create_distributed: " + why); return MG_ERR_COMM; }
+        return create_with_comm(desc, device, rank, nranks, c, out);
+    });
+}
+
+int mg_create_distributed_hostcomm(const mg_desc *desc, int device, int rank, int nranks,
+                                   const mg_host_comm *comm, mg_handle *out)
+{
+    return guarded([&]() -> int {
+        if (!out || !comm) return bad("mg_create_distributed_hostcomm: null argument");
+        *out = nullptr;
+        std::string why;
+        int rc = mg::validate_desc(desc, &why);
+        if (rc) { mg::set_last_error("mg_create_distributed_hostcomm: " + why); return rc; }
+        mg::SlabPlan p;
+        rc = mg::plan_slab(*desc, nranks, rank, 0, &p, &why);
+        if (rc) { mg::set_last_error("mg_create_distributed_hostcomm: " + why); return rc; }
+        mg::Comm *c = mg::make_host_comm(rank, nranks, *comm, &why);
+        if (!c) { mg::set_last_error("mg_create_distributed_hostcomm: " + why); return MG_ERR_COMM; }
+        return create_with_comm(desc, device, rank, nranks, c, out);
+    });
 }
 
 }  // extern "C"

@@ -3,6 +3,7 @@
 // (include/multigrid.hpp:108-145) and the outer loop of src/main.cpp:72-116.
 #include "mg_solver.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -104,7 +105,10 @@ int plan_slab(const mg_desc &d, int nranks, int rank, int level, SlabPlan *out, 
     return MG_OK;
 }
 
-Solver::Solver(const mg_desc &d, int device) : d_(d), device_(device) {}
+Solver::Solver(const mg_desc &d, int device, Comm *comm) : d_(d), device_(device), comm_(comm)
+{
+    if (comm_) { rank_ = comm_->rank; nranks_ = comm_->nranks; }
+}
 
 Solver::~Solver()
 {
@@ -112,6 +116,8 @@ Solver::~Solver()
     for (auto &L : lv_)
         for (auto &b : L.base)
             if (b) (void)hipFree(b);
+    for (auto &f : full_) if (f) (void)hipFree(f);
+    delete comm_;
     if (d_partials_) (void)hipFree(d_partials_);
     if (d_scal_) (void)hipFree(d_scal_);
     if (d_coarse_) (void)hipFree(d_coarse_);
@@ -148,8 +154,35 @@ int Solver::init()
         L.g.pitch = ((n + epl - 1) / epl) * epl;
         L.g.plane = (long long)L.g.ny * L.g.pitch;
         L.g.gz0 = 0; L.g.gnz = L.g.nz;
-        L.alloc_elems = (size_t)(L.g.nz + 2) * (size_t)L.g.plane;
         level_coefficients(d_, l, L.coef);
+        if (nranks_ > 1) {
+            SlabPlan p;
+            std::string why;
+            int rc = plan_slab(d_, nranks_, rank_, l, &p, &why);
+            if (rc) { set_last_error("mg_create_distributed: " + why); return rc; }
+            T_ = p.first_gathered_level - 1;
+            L.dist = l < p.first_gathered_level;
+            L.present = L.dist || rank_ == 0;
+            if (L.dist) {
+                if (l == T_ && rank_ == 0) {  // rank 0 keeps full-size copies of the transition level
+                    gfull_ = L.g;
+                    for (auto &f : full_) {
+                        size_t nbytes = (size_t)(gfull_.nz + 2) * (size_t)gfull_.plane * esize();
+                        MG_HIP(hipMalloc(&f, nbytes));
+                        MG_HIP(hipMemsetAsync(f, 0, nbytes, stream_));
+                        bytes_ += nbytes;
+                    }
+                    max_partials = std::max(max_partials, reduce_partials_capacity(gfull_));
+                }
+                if (l == T_) {
+                    planT_.resize(nranks_);
+                    for (int r = 0; r < nranks_; r++) plan_slab(d_, nranks_, r, l, &planT_[r], &why);
+                }
+                L.g.nz = p.nz; L.g.gz0 = p.z0;
+            }
+        }
+        L.alloc_elems = (size_t)(L.g.nz + 2) * (size_t)L.g.plane;
+        if (!L.present) continue;
         for (int a = 0; a < NUM_ARR; a++) {
             if (a == MG_ARR_RES && l > 0) continue;
             size_t nbytes = L.alloc_elems * esize();
@@ -221,6 +254,79 @@ int Solver::zero_array(int which, int level)
     return MG_OK;
 }
 
+#define MG_TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+int Solver::exchange(int which, int level)
+{
+    Level &L = lv_[level];
+    if (!L.dist) return MG_OK;
+    const size_t pb = (size_t)L.g.plane * esize();
+    char *b = reinterpret_cast<char *>(L.base[which]);
+    P2POp ops[4];
+    int n = 0;
+    if (rank_ > 0) {
+        ops[n++] = P2POp{rank_ - 1, true, b + pb, pb};                       // my first plane -> their upper ghost
+        ops[n++] = P2POp{rank_ - 1, false, b, pb};                           // their last plane -> my lower ghost
+    }
+    if (rank_ < nranks_ - 1) {
+        ops[n++] = P2POp{rank_ + 1, true, b + (size_t)L.g.nz * pb, pb};      // my last plane -> their lower ghost
+        ops[n++] = P2POp{rank_ + 1, false, b + (size_t)(L.g.nz + 1) * pb, pb};
+    }
+    int rc = comm_->batch(ops, n, stream_);
+    if (rc) set_last_error("halo exchange failed");
+    return rc;
+}
+
+int Solver::gather_T(int which, int fullk)
+{
+    Level &L = lv_[T_];
+    const size_t pb = (size_t)L.g.plane * esize();
+    char *b = reinterpret_cast<char *>(L.base[which]);
+    int rc;
+    if (rank_ == 0) {
+        char *f = reinterpret_cast<char *>(full_[fullk]);
+        MG_HIP(hipMemcpyAsync(f + pb, b + pb, (size_t)L.g.nz * pb, hipMemcpyDeviceToDevice, stream_));
+        std::vector<P2POp> ops;
+        for (int r = 1; r < nranks_; r++)
+            ops.push_back(P2POp{r, false, f + (size_t)(1 + planT_[r].z0) * pb, (size_t)planT_[r].nz * pb});
+        rc = comm_->batch(ops.data(), (int)ops.size(), stream_);
+    } else {
+        P2POp op{0, true, b + pb, (size_t)L.g.nz * pb};
+        rc = comm_->batch(&op, 1, stream_);
+    }
+    if (rc) set_last_error("gather to rank 0 failed");
+    return rc;
+}
+
+int Solver::scatter_T(int fullk, int which)
+{
+    Level &L = lv_[T_];
+    const size_t pb = (size_t)L.g.plane * esize();
+    char *b = reinterpret_cast<char *>(L.base[which]);
+    int rc;
+    if (rank_ == 0) {
+        char *f = reinterpret_cast<char *>(full_[fullk]);
+        MG_HIP(hipMemcpyAsync(b + pb, f + pb, (size_t)L.g.nz * pb, hipMemcpyDeviceToDevice, stream_));
+        std::vector<P2POp> ops;
+        for (int r = 1; r < nranks_; r++)
+            ops.push_back(P2POp{r, true, f + (size_t)(1 + planT_[r].z0) * pb, (size_t)planT_[r].nz * pb});
+        rc = comm_->batch(ops.data(), (int)ops.size(), stream_);
+    } else {
+        P2POp op{0, false, b + pb, (size_t)L.g.nz * pb};
+        rc = comm_->batch(&op, 1, stream_);
+    }
+    if (rc) set_last_error("scatter from rank 0 failed");
+    return rc;
+}
+
+int Solver::allreduce(double *dptr, int n)
+{
+    if (nranks_ == 1) return MG_OK;
+    int rc = comm_->allreduce_sum(dptr, n, stream_);
+    if (rc) set_last_error("allreduce failed");
+    return rc;
+}
+
 template <typename T>
 static Coef<T> coef_of(const Level &L)
 {
@@ -244,6 +350,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar)
     switch (smoother) {
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
+            MG_TRY(exchange(ax, level));
             launch_jacobi<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level),
                              ptr<T>(MG_ARR_TMP, level));
             // the reference swaps the std::vector buffers (solvers.hpp:82); so do we
@@ -252,11 +359,17 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar)
         break;
     case MG_SMOOTH_RBGS:
         for (int s = 0; s < sweeps; s++) {
+            MG_TRY(exchange(ax, level));
             launch_rbgs_colour<T>(stream_, L.g, c, 0, ptr<T>(ax, level), ptr<T>(ar, level));
+            MG_TRY(exchange(ax, level));
             launch_rbgs_colour<T>(stream_, L.g, c, 1, ptr<T>(ax, level), ptr<T>(ar, level));
         }
         break;
     default:
+        if (L.dist && sweeps > 0) {
+            set_last_error("lexicographic Gauss-Seidel is sequential across slabs: not available on a distributed level");
+            return MG_ERR_BAD_ARG;
+        }
         if (sweeps > 0) launch_gs_lex<T>(stream_, L.g, c, sweeps, ptr<T>(ax, level), ptr<T>(ar, level));
         break;
     }
@@ -286,10 +399,12 @@ template <typename T>
 int Solver::residual_t(int level, int ax, int ar, int arr_r, bool want_norm)
 {
     Level &L = lv_[level];
+    MG_TRY(exchange(ax, level));
     launch_residual<T>(stream_, L.g, coef_of<T>(L), ptr<T>(ax, level), ptr<T>(ar, level),
                        arr_r >= 0 ? ptr<T>(arr_r, level) : (T *)nullptr, d_partials_,
                        want_norm ? d_scal_ : (double *)nullptr);
     MG_HIP(hipGetLastError());
+    if (want_norm && L.dist) MG_TRY(allreduce(d_scal_, 1));
     return MG_OK;
 }
 
@@ -317,6 +432,7 @@ int Solver::sumsq_t(int level, int arr)
 {
     launch_sumsq<T>(stream_, lv_[level].g, ptr<T>(arr, level), d_partials_, d_scal_ + 1);
     MG_HIP(hipGetLastError());
+    if (lv_[level].dist) MG_TRY(allreduce(d_scal_ + 1, 1));
     return MG_OK;
 }
 
@@ -335,6 +451,11 @@ int Solver::sumsq(int level, int arr, double *out)
 template <typename T>
 int Solver::restrict_t(int fl, int kind, int as, int ad)
 {
+    if (lv_[fl].dist != lv_[fl + 1].dist) {
+        set_last_error("transfer across the gather level is only available inside mg_cycle");
+        return MG_ERR_BAD_ARG;
+    }
+    if (kind == MG_RESTRICT_FULLW) MG_TRY(exchange(as, fl));  // needs r on the lower ghost plane
     if (kind == MG_RESTRICT_FULLW)
         launch_restrict_fw<T>(stream_, lv_[fl].g, lv_[fl + 1].g, ptr<T>(as, fl), ptr<T>(ad, fl + 1));
     else
@@ -358,6 +479,11 @@ int Solver::restrict_to(int fine_level, int kind, int arr_src, int arr_dst)
 template <typename T>
 int Solver::prolong_t(int cl, int add, int as, int ad)
 {
+    if (lv_[cl].dist != lv_[cl - 1].dist) {
+        set_last_error("transfer across the gather level is only available inside mg_cycle");
+        return MG_ERR_BAD_ARG;
+    }
+    MG_TRY(exchange(as, cl));  // odd fine planes read the coarse upper ghost plane
     launch_prolong<T>(stream_, lv_[cl].g, lv_[cl - 1].g, ptr<T>(as, cl), ptr<T>(ad, cl - 1), add != 0);
     MG_HIP(hipGetLastError());
     return MG_OK;
@@ -376,9 +502,9 @@ int Solver::prolong(int coarse_level, int add, int arr_src, int arr_dst)
 }
 
 template <typename T>
-int Solver::correct_t(int au, int ae)
+int Solver::correct_t(int level, int au, int ae)
 {
-    launch_correct<T>(stream_, lv_[0].g, ptr<T>(au, 0), ptr<T>(ae, 0));
+    launch_correct<T>(stream_, lv_[level].g, ptr<T>(au, level), ptr<T>(ae, level));
     MG_HIP(hipGetLastError());
     return MG_OK;
 }
@@ -388,7 +514,7 @@ int Solver::correct(int arr_u, int arr_e)
     if (!check_arr(arr_u, 0, "mg_correct") || !check_arr(arr_e, 0, "mg_correct") || arr_u == arr_e)
         return MG_ERR_BAD_ARG;
     MG_HIP(hipSetDevice(device_));
-    return d_.dtype == MG_F64 ? correct_t<double>(arr_u, arr_e) : correct_t<float>(arr_u, arr_e);
+    return d_.dtype == MG_F64 ? correct_t<double>(0, arr_u, arr_e) : correct_t<float>(0, arr_u, arr_e);
 }
 
 template <typename T>
@@ -438,25 +564,69 @@ int Solver::coarse_solve_ex(int level, int arr_x, int arr_rhs, int smoother, int
     return MG_OK;
 }
 
-#define MG_TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+// Coarse solve of a coarsest level that is still distributed (few levels, many ranks):
+// gather its rhs on rank 0, solve there in the full-size copies, scatter the solution.
+// full_[0] must already hold the gathered rhs.
+template <typename T>
+int Solver::coarse_full_t()
+{
+    if (rank_ != 0) return MG_OK;
+    Level &L = lv_[T_];
+    MG_HIP(hipMemsetAsync(full_[1], 0, (size_t)(gfull_.nz + 2) * (size_t)gfull_.plane * esize(), stream_));
+    launch_coarse_solve<T>(stream_, gfull_, coef_of<T>(L), (T)d_.omega, d_.smoother, fullptr<T>(1), fullptr<T>(2),
+                           fullptr<T>(0), d_.coarse_maxit, d_.coarse_tol, d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0,
+                           d_coarse_);
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+}
 
-// Standard V(nu_pre, nu_post) (extension, BASELINE configs 2-4)
+// Standard V(nu_pre, nu_post) (extension, BASELINE configs 2-4). Slab-decomposed runs: levels
+// 0..T_ are distributed (halo exchanges happen inside smooth_t / residual_t / restrict_t /
+// prolong_t), the residual of level T_ is gathered on rank 0, which runs the deeper levels
+// alone and scatters the prolonged correction back.
 template <typename T>
 int Solver::vcycle_rec_t(int l)
 {
     const int L = d_.levels;
-    if (l == L - 1) return coarse_t<T>(l, MG_ARR_U, MG_ARR_RHS);
-    MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS));
-    MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
-    MG_TRY(restrict_t<T>(l, d_.restriction, MG_ARR_TMP, MG_ARR_RHS));
-    MG_TRY(zero_array(MG_ARR_U, l + 1));
-    MG_TRY(vcycle_rec_t<T>(l + 1));
-    MG_TRY(prolong_t<T>(l + 1, 1, MG_ARR_U, MG_ARR_U));
-    MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS));
+    const bool mine = lv_[l].present;
+    if (l == L - 1) {
+        if (lv_[l].dist) {
+            MG_TRY(gather_T(MG_ARR_RHS, 0));
+            MG_TRY(coarse_full_t<T>());
+            MG_TRY(scatter_T(1, MG_ARR_U));
+            return MG_OK;
+        }
+        return mine ? coarse_t<T>(l, MG_ARR_U, MG_ARR_RHS) : (int)MG_OK;
+    }
+    if (mine) {
+        MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS));
+        MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
+    }
+    if (lv_[l].dist && !lv_[l + 1].dist) {  // l == T_: hand over to rank 0
+        MG_TRY(gather_T(MG_ARR_TMP, 0));
+        if (rank_ == 0) {
+            if (d_.restriction == MG_RESTRICT_FULLW)
+                launch_restrict_fw<T>(stream_, gfull_, lv_[l + 1].g, fullptr<T>(0), ptr<T>(MG_ARR_RHS, l + 1));
+            else
+                launch_inject<T>(stream_, gfull_, lv_[l + 1].g, fullptr<T>(0), ptr<T>(MG_ARR_RHS, l + 1));
+            MG_TRY(zero_array(MG_ARR_U, l + 1));
+            MG_TRY(vcycle_rec_t<T>(l + 1));
+            launch_prolong<T>(stream_, lv_[l + 1].g, gfull_, ptr<T>(MG_ARR_U, l + 1), fullptr<T>(1), false);
+            MG_HIP(hipGetLastError());
+        }
+        MG_TRY(scatter_T(1, MG_ARR_TMP));
+        MG_TRY(correct_t<T>(l, MG_ARR_U, MG_ARR_TMP));  // u += P e, bitwise the same as prolong-add
+    } else if (mine) {
+        MG_TRY(restrict_t<T>(l, d_.restriction, MG_ARR_TMP, MG_ARR_RHS));
+        MG_TRY(zero_array(MG_ARR_U, l + 1));
+        MG_TRY(vcycle_rec_t<T>(l + 1));
+        MG_TRY(prolong_t<T>(l + 1, 1, MG_ARR_U, MG_ARR_U));
+    }
+    if (mine) MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS));
     return MG_OK;
 }
 
-// Enqueues one cycle; no host synchronisation inside.
+// Enqueues one cycle; no host synchronisation inside (RCCL transport).
 template <typename T>
 int Solver::cycle_enqueue_t()
 {
@@ -468,18 +638,44 @@ int Solver::cycle_enqueue_t()
     MG_HIP(hipMemcpyAsync(d_scal_ + 2, d_scal_, sizeof(double), hipMemcpyDeviceToDevice, stream_));
     // every level's rhs is the fine residual seen through mask() (:113,121) = injection
     int src = MG_ARR_RES;
-    for (int l = 0; l + 1 < L; l++) { MG_TRY(restrict_t<T>(l, MG_RESTRICT_INJECT, src, MG_ARR_RHS)); src = MG_ARR_RHS; }
+    for (int l = 0; l + 1 < L; l++) {
+        if (lv_[l].dist && !lv_[l + 1].dist) {
+            MG_TRY(gather_T(src, 0));
+            if (rank_ == 0) {
+                launch_inject<T>(stream_, gfull_, lv_[l + 1].g, fullptr<T>(0), ptr<T>(MG_ARR_RHS, l + 1));
+                MG_HIP(hipGetLastError());
+            }
+        } else if (lv_[l].present) {
+            MG_TRY(restrict_t<T>(l, MG_RESTRICT_INJECT, src, MG_ARR_RHS));
+        }
+        src = MG_ARR_RHS;
+    }
     const int rhsL = (L == 1) ? MG_ARR_RES : MG_ARR_RHS;
     // :128-131 coarse solve from err == 0
-    MG_TRY(zero_array(MG_ARR_E, L - 1));
-    MG_TRY(coarse_t<T>(L - 1, MG_ARR_E, rhsL));
+    if (lv_[L - 1].dist) {
+        MG_TRY(gather_T(rhsL, 0));
+        MG_TRY(coarse_full_t<T>());
+        MG_TRY(scatter_T(1, MG_ARR_E));
+    } else if (lv_[L - 1].present) {
+        MG_TRY(zero_array(MG_ARR_E, L - 1));
+        MG_TRY(coarse_t<T>(L - 1, MG_ARR_E, rhsL));
+    }
     // :134-139 prolong (overwrite) + nu sweeps, coarse to fine
     for (int l = L - 2; l >= 0; l--) {
-        MG_TRY(prolong_t<T>(l + 1, 0, MG_ARR_E, MG_ARR_E));
-        MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_E, l == 0 ? MG_ARR_RES : MG_ARR_RHS));
+        if (lv_[l].dist && !lv_[l + 1].dist) {
+            if (rank_ == 0) {
+                launch_prolong<T>(stream_, lv_[l + 1].g, gfull_, ptr<T>(MG_ARR_E, l + 1), fullptr<T>(1), false);
+                MG_HIP(hipGetLastError());
+            }
+            MG_TRY(scatter_T(1, MG_ARR_E));
+        } else if (lv_[l].present) {
+            MG_TRY(prolong_t<T>(l + 1, 0, MG_ARR_E, MG_ARR_E));
+        }
+        if (lv_[l].present)
+            MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_E, l == 0 ? MG_ARR_RES : MG_ARR_RHS));
     }
     // :141-144
-    MG_TRY(correct_t<T>(MG_ARR_U, MG_ARR_E));
+    MG_TRY(correct_t<T>(0, MG_ARR_U, MG_ARR_E));
     return MG_OK;
 }
 

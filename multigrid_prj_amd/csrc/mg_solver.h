@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/mg_hip.h"
+#include "mg_comm.h"
 #include "mg_geom.h"
 
 namespace mg {
@@ -33,12 +34,14 @@ struct Level {
     size_t alloc_elems = 0;      // (nz + 2) * plane
     void *base[NUM_ARR] = {};    // allocations (ghost plane first)
     double coef[4] = {};
-    bool present = true;         // false: level not held by this rank (gathered elsewhere)
+    bool present = true;         // false: level not held by this rank (gathered on rank 0)
+    bool dist = false;           // true: z-slab of a level distributed over all ranks
 };
 
 class Solver {
 public:
-    Solver(const mg_desc &d, int device);
+    // takes ownership of `comm` (nullptr: single GPU)
+    Solver(const mg_desc &d, int device, Comm *comm = nullptr);
     ~Solver();
     int init();  // allocates; returns mg_status
 
@@ -77,7 +80,13 @@ private:
     template <typename T> int sumsq_t(int level, int arr);
     template <typename T> int restrict_t(int fl, int kind, int as, int ad);
     template <typename T> int prolong_t(int cl, int add, int as, int ad);
-    template <typename T> int correct_t(int au, int ae);
+    template <typename T> int correct_t(int level, int au, int ae);
+    template <typename T> int coarse_full_t();  // coarse solve of a still-distributed coarsest level, gathered
+    int exchange(int which, int level);          // ghost planes <-> z-neighbours
+    int gather_T(int which, int fullk);          // slabs of level T_ -> full_[fullk] on rank 0
+    int scatter_T(int fullk, int which);         // full_[fullk] on rank 0 -> slabs of level T_
+    int allreduce(double *dptr, int n);
+    template <typename T> T *fullptr(int k) const { return reinterpret_cast<T *>(full_[k]) + gfull_.plane; }
     template <typename T> int coarse_t(int level, int ax, int ar);
     template <typename T> int coarse_ex_t(int level, int ax, int ar, int smoother, int maxit, double tol, int fixed);
     template <typename T> int cycle_enqueue_t();
@@ -97,6 +106,13 @@ private:
     double *h_scal_ = nullptr;      // pinned mirrors
     CoarseOut *h_coarse_ = nullptr;
     size_t bytes_ = 0;
+    // slab decomposition (mg_create_distributed*): levels 0..T_ are distributed, deeper
+    // levels live on rank 0; full_[] are rank 0's gathered copies of level T_
+    Comm *comm_ = nullptr;
+    int rank_ = 0, nranks_ = 1, T_ = -1;
+    Geom gfull_{};
+    void *full_[3] = {nullptr, nullptr, nullptr};
+    std::vector<SlabPlan> planT_;
     // in-region timing of the finest-grid smoother (mg_profile_begin/end)
     bool profiling_ = false;
     std::vector<hipEvent_t> prof_ev_;

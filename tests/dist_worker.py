@@ -1,0 +1,59 @@
+"""One rank of a multi-process run, started by tests/test_distributed.py.
+
+    python tests/dist_worker.py <mode> <rank> <world> <port> <case-json> <outdir>
+
+mode "model": CPU only. A numpy model of the slab-decomposed V-cycle -- the partition plan
+  comes from libmg_hip's host-only mg_plan_slab, halos / gather / scatter / norm all-reduce
+  go through torch.distributed (gloo). It checks that plan + communication schedule
+  reproduce the single-rank oracle bit for bit.
+mode "hip": the real distributed solver of libmg_hip (mg_create_distributed_hostcomm) with
+  its exchanges carried by gloo, all ranks sharing GPU 0.
+Rank r writes its slab of the solution and its residual history to <outdir>/rank<r>.npz.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    mode, rank, world, port, case_json, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
+    case = json.loads(case_json)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multigrid_prj_amd import capi
+    kw = dict(case["desc"])
+    desc = capi.make_desc(**kw)
+    n = kw["n"]
+    z0, nz, fg = capi.plan_slab(desc, world, rank, 0)
+    b = np.load(case["rhs"])[z0:z0 + nz]
+    cycles = case["cycles"]
+    if mode == "hip":
+        from multigrid_prj_amd.dist import torch_host_comm
+        s = capi.Solver(desc, device=0, rank=rank, nranks=world, host_comm=torch_host_comm())
+        s.set_rhs(b)
+        for _ in range(cycles):
+            s.cycle()
+        hist, _ = s.solve(0.0, 2)
+        u = s.get_solution()
+        s.close()
+    else:
+        from tests.slab_model import SlabVCycle
+        m = SlabVCycle(desc, rank, world, dist)
+        m.set_rhs(b)
+        for _ in range(cycles):
+            m.cycle()
+        hist = m.solve_hist(2)
+        u = m.solution()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), u=u, hist=np.asarray(hist), z0=z0, nz=nz, fg=fg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

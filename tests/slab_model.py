@@ -1,0 +1,243 @@
+"""numpy model of the z-slab-decomposed V-cycle (CPU, test infrastructure).
+
+Mirrors, operation for operation, what libmg_hip's distributed solver does
+(multigrid_prj_amd/csrc/mg_solver.cpp: exchange before every stencil op, gather of level T
+on rank 0, deeper levels on rank 0 alone, scatter of the prolonged correction), with the
+partition taken from the library's host-only mg_plan_slab. Per-point arithmetic follows the
+oracle's order exactly, so the assembled solution equals the single-rank oracle bit for bit.
+"""
+import numpy as np
+
+from multigrid_prj_amd import capi
+from oracle import pyoracle as po
+
+
+class SlabVCycle:
+    def __init__(self, desc, rank, world, dist):
+        assert desc.dim == 3 and desc.dtype == capi.MG_F64 and desc.cycle == capi.CYCLE_V
+        assert desc.smoother == capi.SMOOTH_JACOBI and desc.coarse_mode == capi.COARSE_FIXED
+        self.d, self.rank, self.world, self.dist = desc, rank, world, dist
+        self.od = po.make_desc(**{f: getattr(desc, f) for f, _ in po.MgDesc._fields_ if f != "aniso"})
+        self.ops = po.Ops(self.od)
+        self.L = desc.levels
+        self.plan = [[capi.plan_slab(desc, world, r, l) for r in range(world)] for l in range(self.L)]
+        self.fg = self.plan[0][0][2]
+        self.T = self.fg - 1
+        self.n = [po.level_n(self.od, l) for l in range(self.L)]
+        self.coef = [po.level_coef(self.od, l) for l in range(self.L)]
+        self.u, self.rhs = {}, {}
+        for l in range(self.L):
+            if l <= self.T:
+                z0, nz, _ = self.plan[l][rank]
+                self.u[l] = np.zeros((nz + 2, self.n[l], self.n[l]))
+                self.rhs[l] = np.zeros((nz, self.n[l], self.n[l]))
+            elif rank == 0:
+                self.u[l] = np.zeros((self.n[l],) * 3)
+                self.rhs[l] = np.zeros((self.n[l],) * 3)
+
+    # ---- communication -------------------------------------------------------------
+    def exchange(self, a):
+        """a: (nz+2, n, n) with ghost planes 0 and -1"""
+        import torch
+        reqs, bufs = [], []
+        r, w = self.rank, self.world
+        if r > 0:
+            s = torch.from_numpy(np.ascontiguousarray(a[1])); g = torch.empty_like(s)
+            reqs += [self.dist.isend(s, r - 1), self.dist.irecv(g, r - 1)]; bufs.append((0, g))
+        if r < w - 1:
+            s = torch.from_numpy(np.ascontiguousarray(a[-2])); g = torch.empty_like(s)
+            reqs += [self.dist.isend(s, r + 1), self.dist.irecv(g, r + 1)]; bufs.append((-1, g))
+        for q in reqs:
+            q.wait()
+        for k, g in bufs:
+            a[k] = g.numpy()
+
+    def gather(self, slab, l):
+        """owned planes (nz,n,n) of level l -> full array on rank 0"""
+        import torch
+        if self.rank == 0:
+            full = np.zeros((self.n[l],) * 3)
+            z0, nz, _ = self.plan[l][0]
+            full[z0:z0 + nz] = slab
+            for r in range(1, self.world):
+                z0, nz, _ = self.plan[l][r]
+                t = torch.empty((nz, self.n[l], self.n[l]), dtype=torch.float64)
+                self.dist.recv(t, r)
+                full[z0:z0 + nz] = t.numpy()
+            return full
+        self.dist.send(torch.from_numpy(np.ascontiguousarray(slab)), 0)
+        return None
+
+    def scatter(self, full, l):
+        import torch
+        z0, nz, _ = self.plan[l][self.rank]
+        if self.rank == 0:
+            for r in range(1, self.world):
+                zr, nr, _ = self.plan[l][r]
+                self.dist.send(torch.from_numpy(np.ascontiguousarray(full[zr:zr + nr])), r)
+            return full[z0:z0 + nz].copy()
+        t = torch.empty((nz, self.n[l], self.n[l]), dtype=torch.float64)
+        self.dist.recv(t, 0)
+        return t.numpy()
+
+    def allreduce(self, x):
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t)
+        return float(t.item())
+
+    # ---- slab operators (oracle operation order, oracle/gmg_ops.inc) -----------------
+    def _bmask(self, l):
+        z0, nz, _ = self.plan[l][self.rank]
+        n = self.n[l]
+        gz = np.arange(z0, z0 + nz)[:, None, None]
+        j = np.arange(n)[None, :, None]
+        i = np.arange(n)[None, None, :]
+        return (gz == 0) | (gz == n - 1) | (j == 0) | (j == n - 1) | (i == 0) | (i == n - 1)
+
+    def _stencil(self, a, l, with_diag):
+        cx, cy, cz, cd = self.coef[l]
+        p = np.pad(a, ((0, 0), (1, 1), (1, 1)))  # zero pad y/x so slices exist (masked out anyway)
+        c = p[1:-1, 1:-1, 1:-1]
+        s = 0.0 + cz * p[:-2, 1:-1, 1:-1]
+        s = s + cy * p[1:-1, :-2, 1:-1]
+        s = s + cx * p[1:-1, 1:-1, :-2]
+        if with_diag:
+            s = s + cd * c
+        s = s + cx * p[1:-1, 1:-1, 2:]
+        s = s + cy * p[1:-1, 2:, 1:-1]
+        s = s + cz * p[2:, 1:-1, 1:-1]
+        return s, c
+
+    def jacobi(self, l):
+        self.exchange(self.u[l])
+        cd, om = self.coef[l][3], self.d.omega
+        s, c = self._stencil(self.u[l], l, False)
+        with np.errstate(all="ignore"):
+            jac = (self.rhs[l] - s) / cd
+            if om != 1.0:
+                jac = c + om * (jac - c)
+        self.u[l][1:-1] = np.where(self._bmask(l), self.rhs[l], jac)
+
+    def residual(self, l):
+        self.exchange(self.u[l])
+        s, c = self._stencil(self.u[l], l, True)
+        s = np.where(self._bmask(l), 1.0 * c, s)
+        return self.rhs[l] - s
+
+    def restrict(self, r_slab, l):
+        """fine residual slab of level l -> rhs slab of level l+1 (both distributed)"""
+        n, nc = self.n[l], self.n[l + 1]
+        z0f, nzf, _ = self.plan[l][self.rank]
+        z0c, nzc, _ = self.plan[l + 1][self.rank]
+        ext = np.zeros((nzf + 2, n, n)); ext[1:-1] = r_slab
+        if self.d.restriction == capi.RESTRICT_FULLW:
+            self.exchange(ext)
+        K = np.arange(z0c, z0c + nzc)
+        fz = 2 * K - z0f + 1  # index into ext
+        inj = ext[fz][:, ::2, ::2]
+        if self.d.restriction != capi.RESTRICT_FULLW:
+            return inj.copy()
+        q, h = 0.25, 0.5
+        # coarse interior i = 1..nc-2 sits at fine 2i: neighbours 2i-1, 2i, 2i+1
+        def wx(a): return q * a[:, :, 1:n - 3:2] + h * a[:, :, 2:n - 2:2] + q * a[:, :, 3:n - 1:2]
+        def wy(a): return q * a[:, 1:n - 3:2, :] + h * a[:, 2:n - 2:2, :] + q * a[:, 3:n - 1:2, :]
+        planes = []
+        for dz in (-1, 0, 1):
+            a = ext[fz[(K > 0) & (K < nc - 1)] + dz]
+            planes.append(wy(wx(a)))
+        fw = q * planes[0] + h * planes[1] + q * planes[2]
+        out = inj.copy()
+        interior = (K > 0) & (K < nc - 1)
+        tmp = out[interior]
+        tmp[:, 1:-1, 1:-1] = fw
+        out[interior] = tmp
+        return out
+
+    def prolong_values(self, l):
+        """P u_{l+1} on this rank's fine planes of level l (coarse level distributed)"""
+        self.exchange(self.u[l + 1])
+        n = self.n[l]
+        z0f, nzf, _ = self.plan[l][self.rank]
+        z0c, _, _ = self.plan[l + 1][self.rank]
+        c = self.u[l + 1]
+        gz = np.arange(z0f, z0f + nzf)
+        vz = np.empty((nzf, c.shape[1], c.shape[2]))
+        ev = gz % 2 == 0
+        vz[ev] = c[gz[ev] // 2 - z0c + 1]
+        od = ~ev
+        k0 = (gz[od] - 1) // 2 - z0c + 1
+        vz[od] = 0.5 * (c[k0] + c[k0 + 1])
+        vy = np.empty((nzf, n, c.shape[2]))
+        vy[:, ::2] = vz
+        vy[:, 1::2] = 0.5 * (vz[:, :-1] + vz[:, 1:])
+        vx = np.empty((nzf, n, n))
+        vx[:, :, ::2] = vy
+        vx[:, :, 1::2] = 0.5 * (vy[:, :, :-1] + vy[:, :, 1:])
+        return vx
+
+    # ---- rank-0-only deeper levels: plain oracle operators ---------------------------
+    def _full_vcycle(self, l):
+        d, ops = self.d, self.ops
+        if l == self.L - 1:
+            self.u[l] = ops.coarse_solve(l, d.smoother, self.u[l], self.rhs[l], maxit=d.coarse_maxit, fixed=True)[0]
+            return
+        self.u[l] = ops.smooth(l, d.smoother, d.nu_pre, self.u[l], self.rhs[l])
+        r = ops.residual(l, self.u[l], self.rhs[l])[0]
+        self.rhs[l + 1] = ops.restrict_fw(r) if d.restriction == capi.RESTRICT_FULLW else ops.inject(r)
+        self.u[l + 1] = np.zeros_like(self.u[l + 1])
+        self._full_vcycle(l + 1)
+        self.u[l] = ops.prolong_add(self.u[l + 1], self.u[l])
+        self.u[l] = ops.smooth(l, d.smoother, d.nu_post, self.u[l], self.rhs[l])
+
+    def _vcycle(self, l):
+        d = self.d
+        if l > self.T:
+            if self.rank == 0:
+                self._full_vcycle(l)
+            return
+        if l == self.L - 1:  # coarsest level still distributed: solve gathered on rank 0
+            full = self.gather(self.rhs[l], l)
+            sol = None
+            if self.rank == 0:
+                sol = self.ops.coarse_solve(l, d.smoother, np.zeros_like(full), full, maxit=d.coarse_maxit, fixed=True)[0]
+            self.u[l][1:-1] = self.scatter(sol, l)
+            return
+        for _ in range(d.nu_pre):
+            self.jacobi(l)
+        r = self.residual(l)
+        if l == self.T:
+            full = self.gather(r, l)
+            e = None
+            if self.rank == 0:
+                ops = self.ops
+                self.rhs[l + 1] = ops.restrict_fw(full) if d.restriction == capi.RESTRICT_FULLW else ops.inject(full)
+                self.u[l + 1] = np.zeros_like(self.u[l + 1])
+                self._full_vcycle(l + 1)
+                e = ops.prolong_overwrite(self.u[l + 1])
+            self.u[l][1:-1] += self.scatter(e, l)
+        else:
+            self.rhs[l + 1] = self.restrict(r, l)
+            self.u[l + 1][:] = 0.0
+            self._vcycle(l + 1)
+            self.u[l][1:-1] += self.prolong_values(l)
+        for _ in range(d.nu_post):
+            self.jacobi(l)
+
+    # ---- driver ------------------------------------------------------------------------
+    def set_rhs(self, b):
+        self.rhs[0][:] = b
+
+    def cycle(self):
+        self._vcycle(0)
+
+    def solution(self):
+        return self.u[0][1:-1].copy()
+
+    def solve_hist(self, k):
+        nb = self.allreduce(float((self.rhs[0] ** 2).sum()))
+        hist = [np.sqrt(self.allreduce(float((self.residual(0) ** 2).sum())) / nb)]
+        for _ in range(k):
+            self.cycle()
+            hist.append(np.sqrt(self.allreduce(float((self.residual(0) ** 2).sum())) / nb))
+        return hist
