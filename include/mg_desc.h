@@ -53,6 +53,11 @@ typedef struct mg_desc {
     double  coarse_tol;   /* reference 1e-1                                              */
     double  aniso[3];     /* per-axis multipliers of alpha, order {x(fast), y, z(slow)};
                              {1,1,1} == isotropic reference operator                     */
+    int32_t dist_min_n;   /* multi-GPU only: levels with fewer nodes per side than this are
+                             gathered on rank 0 instead of being slab-decomposed.
+                             0 = default (257: below that a halo exchange costs more than the
+                             sweep it feeds)                                */
+    int32_t reserved_;
 } mg_desc;
 
 /* Fills *d with the reference defaults for a 2-D run (`Multigrid -n n -ml levels …`). */
@@ -66,6 +71,7 @@ static inline void mg_desc_reference_defaults(mg_desc *d, int n, int levels,
     d->coarse_mode = MG_COARSE_TOL; d->coarse_maxit = 2000; d->outer_pre_gs = 2;
     d->coarse_tol = 1e-1;
     d->aniso[0] = d->aniso[1] = d->aniso[2] = 1.0;
+    d->dist_min_n = 0; d->reserved_ = 0;
 }
 
 /* per-cycle statistics returned by mg_cycle / orc_mg_cycle */

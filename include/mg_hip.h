@@ -132,6 +132,9 @@ int mg_device_bytes(mg_handle h, size_t *bytes);
 /* rank 0 creates the RCCL unique id; the caller ships it to the other ranks by any
  * means (bench.py: torch.distributed broadcast) */
 int mg_comm_unique_id(void *id128);
+/* single-process smoke test of the RCCL transport on the current device: communicator of
+ * one rank, grouped send/recv to self of `bytes` bytes, all-reduce of one double */
+int mg_comm_selftest(size_t bytes);
 /* like mg_create, for rank `rank` of `nranks` (one process per GPU) */
 int mg_create_distributed(const mg_desc *desc, int device, int rank, int nranks,
                           const void *id128, mg_handle *out);

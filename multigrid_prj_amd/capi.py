@@ -39,6 +39,7 @@ class MgDesc(C.Structure):
         ("coarse_maxit", C.c_int32), ("outer_pre_gs", C.c_int32),
         ("coarse_tol", C.c_double),
         ("aniso", C.c_double * 3),
+        ("dist_min_n", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -52,7 +53,7 @@ class MgCycleStats(C.Structure):
 def make_desc(dim=2, n=17, levels=2, dtype=MG_F64, length=10.0, alpha=1.0,
               cycle=CYCLE_SAWTOOTH, smoother=SMOOTH_JACOBI, omega=1.0, nu_pre=0, nu_post=5,
               restriction=RESTRICT_INJECT, coarse_mode=COARSE_TOL, coarse_maxit=2000,
-              outer_pre_gs=2, coarse_tol=1e-1, aniso=(1.0, 1.0, 1.0)) -> MgDesc:
+              outer_pre_gs=2, coarse_tol=1e-1, aniso=(1.0, 1.0, 1.0), dist_min_n=0) -> MgDesc:
     """Defaults are the reference program's hard-coded values (include/mg_desc.h)."""
     d = MgDesc()
     d.dim, d.n, d.levels, d.dtype = dim, n, levels, dtype
@@ -62,6 +63,7 @@ def make_desc(dim=2, n=17, levels=2, dtype=MG_F64, length=10.0, alpha=1.0,
     d.restriction, d.coarse_mode = restriction, coarse_mode
     d.coarse_maxit, d.outer_pre_gs, d.coarse_tol = coarse_maxit, outer_pre_gs, coarse_tol
     d.aniso[0], d.aniso[1], d.aniso[2] = aniso
+    d.dist_min_n = dist_min_n
     return d
 
 
@@ -83,7 +85,7 @@ EXPORTS = [
     "mg_level_coefficients", "mg_set_rhs", "mg_set_solution", "mg_get_solution", "mg_set_array",
     "mg_get_array", "mg_zero_array", "mg_smooth", "mg_residual", "mg_sumsq", "mg_restrict",
     "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_coarse_solve_ex", "mg_cycle", "mg_cycle_async", "mg_solve",
-    "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_device_bytes", "mg_comm_unique_id",
+    "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_device_bytes", "mg_comm_unique_id", "mg_comm_selftest",
     "mg_create_distributed", "mg_create_distributed_hostcomm", "mg_plan_slab",
 ]
 
@@ -132,6 +134,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.mg_profile_end.argtypes = [vp, dp, C.POINTER(i)]
     L.mg_device_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.mg_comm_unique_id.argtypes = [vp]
+    L.mg_comm_selftest.argtypes = [C.c_size_t]
     L.mg_create_distributed.argtypes = [C.POINTER(MgDesc), i, i, i, vp, C.POINTER(vp)]
     L.mg_create_distributed_hostcomm.argtypes = [C.POINTER(MgDesc), i, i, i, C.POINTER(MgHostComm), C.POINTER(vp)]
     L.mg_plan_slab.argtypes = [C.POINTER(MgDesc), i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
@@ -155,6 +158,11 @@ def plan_slab(desc: MgDesc, nranks: int, rank: int, level: int):
     z0, nz, fg = C.c_int(0), C.c_int(0), C.c_int(0)
     _check(load().mg_plan_slab(C.byref(desc), nranks, rank, level, C.byref(z0), C.byref(nz), C.byref(fg)))
     return z0.value, nz.value, fg.value
+
+
+def comm_selftest(nbytes: int = 1 << 20):
+    """RCCL transport smoke test on the current device (one rank, send/recv to self)."""
+    _check(load().mg_comm_selftest(nbytes))
 
 
 def comm_unique_id() -> bytes:

@@ -184,6 +184,43 @@ int mg_comm_unique_id(void *id128)
     return rc;
 }
 
+int mg_comm_selftest(size_t bytes)
+{
+    return guarded([&]() -> int {
+        char id[MG_COMM_ID_BYTES];
+        std::string why;
+        int rc = mg::rccl_unique_id(id, &why);
+        if (rc) { mg::set_last_error("mg_comm_selftest: " + why); return rc; }
+        mg::Comm *c = mg::make_rccl_comm(0, 1, id, &why);
+        if (!c) { mg::set_last_error("mg_comm_selftest: " + why); return MG_ERR_COMM; }
+        struct Guard { mg::Comm *c; ~Guard() { delete c; } } g{c};
+        hipStream_t s;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return bad("stream");
+        char *a = nullptr, *b = nullptr;
+        double *d = nullptr;
+        if (hipMalloc((void **)&a, bytes) != hipSuccess || hipMalloc((void **)&b, bytes) != hipSuccess ||
+            hipMalloc((void **)&d, sizeof(double)) != hipSuccess) return bad("alloc");
+        (void)hipMemsetAsync(a, 0x5a, bytes, s);
+        (void)hipMemsetAsync(b, 0, bytes, s);
+        double one = 1.25;
+        (void)hipMemcpyAsync(d, &one, sizeof(double), hipMemcpyHostToDevice, s);
+        mg::P2POp ops[2] = {{0, true, a, bytes}, {0, false, b, bytes}};
+        rc = c->batch(ops, 2, s);
+        if (!rc) rc = c->allreduce_sum(d, 1, s);
+        std::string hb(bytes, 0);
+        double out = 0;
+        (void)hipMemcpyAsync(&hb[0], b, bytes, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(&out, d, sizeof(double), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(a); (void)hipFree(b); (void)hipFree(d); (void)hipStreamDestroy(s);
+        if (rc) { mg::set_last_error("mg_comm_selftest: transport call failed"); return rc; }
+        for (size_t i = 0; i < bytes; i++)
+            if (hb[i] != 0x5a) { mg::set_last_error("mg_comm_selftest: payload mismatch"); return MG_ERR_COMM; }
+        if (out != 1.25) { mg::set_last_error("mg_comm_selftest: all-reduce mismatch"); return MG_ERR_COMM; }
+        return MG_OK;
+    });
+}
+
 static int create_with_comm(const mg_desc *desc, int device, int rank, int nranks, mg::Comm *comm, mg_handle *out)
 {
     (void)rank; (void)nranks;

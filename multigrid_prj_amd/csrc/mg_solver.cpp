@@ -78,13 +78,15 @@ int plan_slab(const mg_desc &d, int nranks, int rank, int level, SlabPlan *out, 
     if (level < 0 || level >= d.levels) return fail("bad level");
     if (nranks > 1 && d.dim != 3) return fail("domain decomposition needs dim == 3");
     // Distributed levels 0..Ld-1: every rank keeps >= 2 coarse cells and the level has
-    // >= 33 nodes per side; coarser levels are agglomerated on rank 0.
+    // >= dist_min_n nodes per side; coarser levels are agglomerated on rank 0.
+    // Level 0 is always distributed (that is what the ranks are for).
+    const int min_n = d.dist_min_n > 0 ? d.dist_min_n : 257;
     int Ld = d.levels;
     if (nranks > 1) {
         Ld = 0;
         for (int l = 0; l < d.levels; l++) {
             int cells = (d.n - 1) >> l;
-            if (cells >= 2 * nranks && cells + 1 >= 33) Ld = l + 1; else break;
+            if (cells >= 2 * nranks && (l == 0 || cells + 1 >= min_n)) Ld = l + 1; else break;
         }
         if (Ld == 0) return fail("grid too small for this many ranks");
     }

@@ -35,6 +35,7 @@ class MgDesc(C.Structure):
         ("coarse_maxit", C.c_int32), ("outer_pre_gs", C.c_int32),
         ("coarse_tol", C.c_double),
         ("aniso", C.c_double * 3),
+        ("dist_min_n", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -48,7 +49,7 @@ class MgCycleStats(C.Structure):
 def make_desc(dim=2, n=17, levels=2, dtype=MG_F64, length=10.0, alpha=1.0,
               cycle=CYCLE_SAWTOOTH, smoother=SMOOTH_JACOBI, omega=1.0, nu_pre=0, nu_post=5,
               restriction=RESTRICT_INJECT, coarse_mode=COARSE_TOL, coarse_maxit=2000,
-              outer_pre_gs=2, coarse_tol=1e-1, aniso=(1.0, 1.0, 1.0)) -> MgDesc:
+              outer_pre_gs=2, coarse_tol=1e-1, aniso=(1.0, 1.0, 1.0), dist_min_n=0) -> MgDesc:
     """Defaults == the reference program's hard-coded values (include/mg_desc.h)."""
     d = MgDesc()
     d.dim, d.n, d.levels, d.dtype = dim, n, levels, dtype
@@ -58,6 +59,7 @@ def make_desc(dim=2, n=17, levels=2, dtype=MG_F64, length=10.0, alpha=1.0,
     d.restriction, d.coarse_mode = restriction, coarse_mode
     d.coarse_maxit, d.outer_pre_gs, d.coarse_tol = coarse_maxit, outer_pre_gs, coarse_tol
     d.aniso[0], d.aniso[1], d.aniso[2] = aniso
+    d.dist_min_n = dist_min_n
     return d
 
 

@@ -56,7 +56,7 @@ def test_product_package_never_touches_the_oracle():
 
 @pytest.mark.parametrize("n,levels,nranks", [(513, 6, 8), (513, 6, 4), (513, 6, 2), (1025, 7, 8), (257, 5, 8), (129, 3, 3)])
 def test_slab_plan_partitions_every_level(n, levels, nranks):
-    d = capi.make_desc(dim=3, n=n, levels=levels)
+    d = capi.make_desc(dim=3, n=n, levels=levels, dist_min_n=33)
     fg = capi.plan_slab(d, nranks, 0, 0)[2]
     assert 1 <= fg <= levels
     for l in range(levels):
@@ -76,6 +76,14 @@ def test_slab_plan_partitions_every_level(n, levels, nranks):
                 assert all(z0 <= 2 * k < z0 + nz for k in range(zc, zc + nzc))
         if l < fg:
             assert covered == nl
+
+
+def test_slab_plan_default_gathers_latency_bound_levels():
+    """Default threshold: only levels with >= 257 nodes per side stay distributed."""
+    d = capi.make_desc(dim=3, n=513, levels=6)
+    assert capi.plan_slab(d, 8, 0, 0)[2] == 2      # 513^3 and 257^3 distributed, 129^3.. on rank 0
+    d = capi.make_desc(dim=3, n=129, levels=3)
+    assert capi.plan_slab(d, 2, 0, 0)[2] == 1      # the finest level is always distributed
 
 
 def test_slab_plan_single_rank_and_errors():

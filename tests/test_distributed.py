@@ -54,7 +54,8 @@ def _run_ranks(mode, world, case, tmp_path, timeout=600):
 
 def _case(tmp_path, n, levels, restriction, cycles=2):
     desc = dict(dim=3, n=n, levels=levels, dtype=0, length=1.0, alpha=1.0, cycle=1, smoother=1, omega=6 / 7,
-                nu_pre=2, nu_post=2, restriction=restriction, coarse_mode=1, coarse_maxit=20, outer_pre_gs=0)
+                nu_pre=2, nu_post=2, restriction=restriction, coarse_mode=1, coarse_maxit=20, outer_pre_gs=0,
+                dist_min_n=33)
     b = po.fill_rhs_3d(n, 1.0, 1.0, 1)
     rhs = os.path.join(tmp_path, "rhs.npy")
     np.save(rhs, b)
@@ -102,3 +103,11 @@ def test_hip_distributed_solver_two_processes_one_gpu(world, n, levels, restrict
     assert np.array_equal(u, u_ref)
     for h in hists:
         np.testing.assert_allclose(h, h1, rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_rccl_transport_selftest():
+    """The product transport (RCCL) cannot run two ranks on one GPU; at least exercise
+    communicator creation, grouped ncclSend/ncclRecv and ncclAllReduce on this device."""
+    from multigrid_prj_amd import capi
+    capi.comm_selftest(1 << 20)
