@@ -463,6 +463,140 @@ __global__ __launch_bounds__(SWG) void k_coarse_solve(Geom g, Coef<T> c, T omega
     }
 }
 
+// ---------------------------------------------------------------- LDS-resident coarse solver
+// Same loop as k_coarse_solve with the three coarse arrays (x, Jacobi temp, rhs) held in LDS
+// for the whole solve: 17^3 or 65^2 doubles x 3 = 118 / 101 KB of the CU's 160 KB. Each
+// thread owns <= PT fixed points whose dense indices and boundary flags are computed once,
+// so an iteration is LDS loads + the stencil + one wave-shuffle reduction and two barriers:
+// no global memory, no integer division, no launch per iteration.
+template <typename T, int DIM, int PT>
+__global__ __launch_bounds__(SWG) void k_coarse_solve_lds(Geom g, Coef<T> c, T omega, int smoother, T *x,
+                                                          const T *rhs, int maxit, double tol, int fixed,
+                                                          CoarseOut *out)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ double part[2][SWG / 64];
+    const int npl = g.nx * g.ny;
+    const int total = npl * g.nz;
+    T *sx = reinterpret_cast<T *>(smem_raw);
+    T *st = sx + total;
+    T *sr = st + total;
+    Geom gl = g;  // dense LDS geometry
+    gl.pitch = g.nx;
+    gl.plane = npl;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int pidx[PT];
+    bool pbnd[PT];
+    int np = 0;
+#pragma unroll
+    for (int k = 0; k < PT; k++) {
+        int q = tid + k * SWG;
+        pidx[k] = 0; pbnd[k] = true;
+        if (q < total) {
+            int z = q / npl, rem = q - z * npl, y = rem / g.nx, xx = rem - y * g.nx;
+            long long gi = lidx(g, z, y, xx);
+            pidx[k] = q;
+            pbnd[k] = on_boundary(g, z, y, xx);
+            sx[q] = x[gi];
+            sr[q] = rhs[gi];
+            np = k + 1;
+        }
+    }
+    int parity = 0;
+    auto block_sum = [&](double v) -> double {
+        v = wave_sum(v);
+        if (lane == 0) part[parity][wv] = v;
+        __syncthreads();
+        double sum = 0;
+#pragma unroll
+        for (int w = 0; w < SWG / 64; w++) sum += part[parity][w];
+        parity ^= 1;
+        return sum;
+    };
+    const bool damped = (omega != (T)1);
+    auto residual_sumsq = [&]() -> double {
+        double sq = 0.;
+#pragma unroll
+        for (int k = 0; k < PT; k++) {
+            if (k < np) {
+                const int i = pidx[k];
+                T sum;
+                if (pbnd[k]) sum = (T)1 * sx[i];
+                else sum = full_sum<T, DIM>(sx, i, gl.pitch, gl.plane, c);
+                T res = sr[i] - sum;
+                sq += (double)res * (double)res;
+            }
+        }
+        return block_sum(sq);
+    };
+    auto sweep = [&]() {
+        if (smoother == 1) {
+#pragma unroll
+            for (int k = 0; k < PT; k++) {
+                if (k < np) {
+                    const int i = pidx[k];
+                    T b = sr[i], r = b;
+                    if (!pbnd[k]) {
+                        T sum = offdiag_sum<T, DIM>(sx, i, gl.pitch, gl.plane, c);
+                        T jac = (b - sum) / c.cd;
+                        r = damped ? sx[i] + omega * (jac - sx[i]) : jac;
+                    }
+                    st[i] = r;
+                }
+            }
+            __syncthreads();
+            T *t = sx; sx = st; st = t;
+        } else if (smoother == 2) {
+            wg_rbgs<T, DIM>(gl, c, sx, sr);
+        } else {
+            wg_gs_lex<T, DIM>(gl, c, sx, sr);
+        }
+    };
+    __syncthreads();
+    double sqb = 0.;
+#pragma unroll
+    for (int k = 0; k < PT; k++)
+        if (k < np) { double t = (double)sr[pidx[k]]; sqb += t * t; }
+    const double nb = block_sum(sqb);
+    int iters = 0, flag = 0;
+    double nr;
+    if (fixed) {
+        for (int s = 0; s < maxit; s++) sweep();
+        iters = maxit;
+        nr = residual_sumsq();
+    } else {
+        int counter = maxit;
+        nr = residual_sumsq();
+        while (sqrt(nr / nb) > tol) {
+            if (counter > 0) {
+                sweep();
+                counter -= 1;
+                iters++;
+                nr = residual_sumsq();
+            } else {
+                flag = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PT; k++) {
+        int q = tid + k * SWG;
+        if (q < total) {
+            int z = q / npl, rem = q - z * npl, y = rem / g.nx, xx = rem - y * g.nx;
+            x[lidx(g, z, y, xx)] = sx[q];
+        }
+    }
+    if (tid == 0) {
+        out->iters = iters;
+        out->flag = flag;
+        out->relres = sqrt(nr / nb);
+        out->sumsq_rhs = nb;
+        out->sumsq_r = nr;
+    }
+}
+
 inline dim3 grid_for(int nx, int ny, int nz)
 {
     return dim3((nx + BX - 1) / BX, (ny + BY - 1) / BY, nz);
@@ -581,17 +715,39 @@ void launch_correct(hipStream_t s, const Geom &g, T *u, T *e)
     hipLaunchKernelGGL((k_correct<T>), gr, bl, 0, s, g, u, e);
 }
 
+template <typename T, int DIM, int PT>
+static bool try_launch_coarse_lds(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, int smoother, T *x,
+                                  const T *rhs, int maxit, double tol, int fixed, CoarseOut *d_out)
+{
+    const size_t total = (size_t)g.nx * g.ny * g.nz;
+    const size_t bytes = 3 * total * sizeof(T);
+    if (total > (size_t)PT * SWG || bytes > (size_t)150 * 1024) return false;
+    auto kern = k_coarse_solve_lds<T, DIM, PT>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                150 * 1024) != hipSuccess) return false;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(SWG), bytes, s, g, c, omega, smoother, x, rhs, maxit, tol, fixed, d_out);
+    return true;
+}
+
 template <typename T>
 void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, int smoother,
                          T *x, T *tmp, const T *rhs, int maxit, double tol, int fixed,
                          CoarseOut *d_out)
 {
-    if (g.dim == 3)
+    // LDS-resident when the three arrays fit one CU's LDS, global-memory loop otherwise
+    if (g.dim == 3) {
+        if (try_launch_coarse_lds<T, 3, 5>(s, g, c, omega, smoother, x, rhs, maxit, tol, fixed, d_out)) return;
         hipLaunchKernelGGL((k_coarse_solve<T, 3>), dim3(1), dim3(SWG), 0, s, g, c, omega, smoother, x,
                            tmp, rhs, maxit, tol, fixed, d_out);
-    else
+    } else {
+        if (try_launch_coarse_lds<T, 2, 5>(s, g, c, omega, smoother, x, rhs, maxit, tol, fixed, d_out)) return;
         hipLaunchKernelGGL((k_coarse_solve<T, 2>), dim3(1), dim3(SWG), 0, s, g, c, omega, smoother, x,
                            tmp, rhs, maxit, tol, fixed, d_out);
+    }
 }
 
 #define MG_INSTANTIATE(T)                                                                          \
