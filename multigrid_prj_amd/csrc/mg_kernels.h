@@ -26,6 +26,11 @@ template <typename T>
 int launch_residual_fast(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs,
                          T *r, double *d_partials, bool want_norm);
 
+// 3-D prolongation fast path (mg_transfer_fast.hip)
+template <typename T> bool prolong_fast_ok(const Geom &gc, const Geom &gf);
+template <typename T>
+void launch_prolong_fast(hipStream_t s, const Geom &gc, const Geom &gf, const T *coarse, T *fine, bool add);
+
 // one colour half-sweep of red-black Gauss-Seidel, in place
 template <typename T>
 void launch_rbgs_colour(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u,

@@ -698,6 +698,7 @@ template <typename T>
 void launch_prolong(hipStream_t s, const Geom &gc, const Geom &gf, const T *coarse, T *fine,
                     bool add)
 {
+    if (prolong_fast_ok<T>(gc, gf)) { launch_prolong_fast<T>(s, gc, gf, coarse, fine, add); return; }
     dim3 gr = grid_for(gf.nx, gf.ny, gf.nz), bl(BX, BY, 1);
     if (gf.dim == 3) {
         if (add) hipLaunchKernelGGL((k_prolong<T, 3, true>), gr, bl, 0, s, gc, gf, coarse, fine);
