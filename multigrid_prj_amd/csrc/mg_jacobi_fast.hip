@@ -58,14 +58,19 @@ __device__ __forceinline__ double wave_sum64(double v)
     return v;
 }
 
-enum { OP_JACOBI = 0, OP_RESIDUAL = 1 };
+enum { OP_JACOBI = 0, OP_RESIDUAL = 1, OP_RB = 2 };
 
 constexpr int RY = 2, BW = 4, ZC = 3;
 
 // OP_JACOBI : out = Jacobi update (DAMPED selects omega != 1)
 // OP_RESIDUAL: out = rhs - A u (stored if SAVE), sum r^2 -> partials[block] if NORM
-template <typename T, int OP, bool DAMPED, bool SAVE, bool NORM, bool NTLOAD>
-__global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
+// OP_RB     : one colour half-sweep of red-black Gauss-Seidel, out of place: points with
+//             (x+y+gz)&1 == colour get the Gauss-Seidel update, the others are copied, so
+//             red: u -> tmp, black: tmp -> u leaves the sweep's result in u
+// ZEROU     : u is identically zero (first pre-smoothing sweep of a coarse level): nothing
+//             is loaded for it, which also saves the memset of the initial guess
+template <typename T, int OP, bool DAMPED, bool SAVE, bool NORM, bool NTLOAD, bool ZEROU = false>
+__global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega, int colour,
                                                      const T *__restrict__ u,
                                                      const T *__restrict__ rhs, T *__restrict__ out,
                                                      double *__restrict__ partials, int nbx, int nby,
@@ -109,27 +114,27 @@ __global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
         const T *pz = u + (long long)z0 * g.plane;
 #pragma unroll
         for (int r = 0; r < RY; r++) {
-            zm[r] = *(const vec *)(pz - g.plane + rowoff[r]);
-            cc[r] = *(const vec *)(pz + rowoff[r]);
+            zm[r] = ZEROU ? (vec)(0) : *(const vec *)(pz - g.plane + rowoff[r]);
+            cc[r] = ZEROU ? (vec)(0) : *(const vec *)(pz + rowoff[r]);
         }
         for (int z = z0; z < zend; z++, pz += g.plane) {
             const long long zo = (long long)z * g.plane;
             vec b[RY];
 #pragma unroll
             for (int r = 0; r < RY; r++) {
-                zp[r] = *(const vec *)(pz + g.plane + rowoff[r]);
+                zp[r] = ZEROU ? (vec)(0) : *(const vec *)(pz + g.plane + rowoff[r]);
                 if (NTLOAD) b[r] = __builtin_nontemporal_load((const vec *)(rhs + zo + rowoff[r]));
                 else b[r] = *(const vec *)(rhs + zo + rowoff[r]);
             }
-            const vec hlo = *(const vec *)(pz + off_lo);
-            const vec hhi = *(const vec *)(pz + off_hi);
+            const vec hlo = ZEROU ? (vec)(0) : *(const vec *)(pz + off_lo);
+            const vec hhi = ZEROU ? (vec)(0) : *(const vec *)(pz + off_hi);
             const int gz = g.gz0 + z;
             const bool zb = (gz == 0) || (gz == g.gnz - 1);
 #pragma unroll
             for (int r = 0; r < RY; r++) {
                 T el = 0, er = 0;
-                if (lane == 0) el = pz[rowoff[r] - 1];
-                if (lane == 63) er = pz[rowoff[r] + V];
+                if (!ZEROU && lane == 0) el = pz[rowoff[r] - 1];
+                if (!ZEROU && lane == 63) er = pz[rowoff[r] + V];
                 const T xm = from_prev_lane(cc[r][V - 1], el);
                 const T xp = from_next_lane(cc[r][0], er);
                 const vec ym = (r > 0) ? cc[r > 0 ? r - 1 : 0] : hlo;
@@ -153,13 +158,17 @@ __global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
                         T jac = (b[r][e] - sum) / c.cd;
                         if (DAMPED) jac = cc[r][e] + omega * (jac - cc[r][e]);
                         res[e] = bnd ? b[r][e] : jac;
+                    } else if (OP == OP_RB) {
+                        const T gs = (b[r][e] - sum) / c.cd;
+                        const bool mine = ((x0 + e + yb + r + gz) & 1) == colour;
+                        res[e] = mine ? (bnd ? b[r][e] : gs) : cc[r][e];
                     } else {
                         if (bnd) sum = (T)1 * cc[r][e];
                         res[e] = b[r][e] - sum;
                     }
                 }
                 if (xin && yin[r]) {
-                    if (OP == OP_JACOBI || SAVE) __builtin_nontemporal_store(res, (vec *)(out + zo + rowoff[r]));
+                    if (OP != OP_RESIDUAL || SAVE) __builtin_nontemporal_store(res, (vec *)(out + zo + rowoff[r]));
                     if (NORM) {
 #pragma unroll
                         for (int e = 0; e < V; e++) sq += (double)res[e] * (double)res[e];
@@ -175,10 +184,12 @@ __global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
                     T tb = 0, tres = 0;
                     if (j == 0) {
                         tb = rhs[ro + g.nx - 1];
-                        tres = (OP == OP_JACOBI) ? tb : tb - (T)1 * pz[(rowoff[r] - x0c) + g.nx - 1];
+                        if (OP == OP_JACOBI) tres = tb;
+                        else if (OP == OP_RB) tres = (((g.nx - 1 + yb + r + gz) & 1) == colour) ? tb : pz[(rowoff[r] - x0c) + g.nx - 1];
+                        else tres = tb - (T)1 * (ZEROU ? (T)0 : pz[(rowoff[r] - x0c) + g.nx - 1]);
                         if (NORM) sq += (double)tres * (double)tres;
                     }
-                    if (xs < line_end && (OP == OP_JACOBI || SAVE)) {
+                    if (xs < line_end && (OP != OP_RESIDUAL || SAVE)) {
                         vec tv = (vec)(0);
                         tv[0] = tres;
                         __builtin_nontemporal_store(tv, (vec *)(out + ro + xs));
@@ -236,15 +247,30 @@ static bool stream_level(const Geom &g, size_t esize) { return (size_t)g.nz * g.
 
 template <typename T>
 void launch_jacobi_fast(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u,
-                        const T *rhs, T *out)
+                        const T *rhs, T *out, bool zero_u)
 {
     FastGrid f = fast_grid<T>(g);
     const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
     dim3 gr(f.grid), bl(64 * BW);
-#define MG_J(D, N) hipLaunchKernelGGL((k_sweep3d<T, OP_JACOBI, D, true, false, N>), gr, bl, 0, s, g, c, omega, u, rhs, out, (double *)nullptr, f.nbx, f.nby, f.nbz)
-    if (damped) { if (nt) MG_J(true, true); else MG_J(true, false); }
-    else { if (nt) MG_J(false, true); else MG_J(false, false); }
+#define MG_J(D, N, Z) hipLaunchKernelGGL((k_sweep3d<T, OP_JACOBI, D, true, false, N, Z>), gr, bl, 0, s, g, c, omega, 0, u, rhs, out, (double *)nullptr, f.nbx, f.nby, f.nbz)
+    if (zero_u) {
+        if (damped) { if (nt) MG_J(true, true, true); else MG_J(true, false, true); }
+        else { if (nt) MG_J(false, true, true); else MG_J(false, false, true); }
+    } else {
+        if (damped) { if (nt) MG_J(true, true, false); else MG_J(true, false, false); }
+        else { if (nt) MG_J(false, true, false); else MG_J(false, false, false); }
+    }
 #undef MG_J
+}
+
+template <typename T>
+void launch_rb_fast(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, const T *u, const T *rhs, T *out)
+{
+    FastGrid f = fast_grid<T>(g);
+    const bool nt = stream_level(g, sizeof(T));
+    dim3 gr(f.grid), bl(64 * BW);
+    if (nt) hipLaunchKernelGGL((k_sweep3d<T, OP_RB, false, true, false, true>), gr, bl, 0, s, g, c, (T)1, colour, u, rhs, out, (double *)nullptr, f.nbx, f.nby, f.nbz);
+    else hipLaunchKernelGGL((k_sweep3d<T, OP_RB, false, true, false, false>), gr, bl, 0, s, g, c, (T)1, colour, u, rhs, out, (double *)nullptr, f.nbx, f.nby, f.nbz);
 }
 
 // returns the number of per-block partials written (0 when no norm was requested)
@@ -255,7 +281,7 @@ int launch_residual_fast(hipStream_t s, const Geom &g, const Coef<T> &c, const T
     FastGrid f = fast_grid<T>(g);
     const bool nt = stream_level(g, sizeof(T));
     dim3 gr(f.grid), bl(64 * BW);
-#define MG_R(S, NO, N) hipLaunchKernelGGL((k_sweep3d<T, OP_RESIDUAL, false, S, NO, N>), gr, bl, 0, s, g, c, (T)1, u, rhs, r, d_partials, f.nbx, f.nby, f.nbz)
+#define MG_R(S, NO, N) hipLaunchKernelGGL((k_sweep3d<T, OP_RESIDUAL, false, S, NO, N>), gr, bl, 0, s, g, c, (T)1, 0, u, rhs, r, d_partials, f.nbx, f.nby, f.nbz)
     if (r && want_norm) { if (nt) MG_R(true, true, true); else MG_R(true, true, false); }
     else if (r) { if (nt) MG_R(true, false, true); else MG_R(true, false, false); }
     else { if (nt) MG_R(false, true, true); else MG_R(false, true, false); }
@@ -267,8 +293,10 @@ template bool fast_path_ok<double>(const Geom &);
 template bool fast_path_ok<float>(const Geom &);
 template int fast_partials_capacity<double>(const Geom &);
 template int fast_partials_capacity<float>(const Geom &);
-template void launch_jacobi_fast<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *);
-template void launch_jacobi_fast<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *);
+template void launch_jacobi_fast<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *, bool);
+template void launch_jacobi_fast<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *, bool);
+template void launch_rb_fast<double>(hipStream_t, const Geom &, const Coef<double> &, int, const double *, const double *, double *);
+template void launch_rb_fast<float>(hipStream_t, const Geom &, const Coef<float> &, int, const float *, const float *, float *);
 template int launch_residual_fast<double>(hipStream_t, const Geom &, const Coef<double> &, const double *, const double *, double *, double *, bool);
 template int launch_residual_fast<float>(hipStream_t, const Geom &, const Coef<float> &, const float *, const float *, float *, double *, bool);
 

@@ -11,9 +11,11 @@ namespace mg {
 // number of per-block partial sums a reduction launch over `g` may produce
 int reduce_partials_capacity(const Geom &g);
 
+// zero_u: the caller guarantees u == 0 everywhere (fresh coarse-level initial guess); the fast
+// path then reads nothing of u. The generic path needs u to really hold zeros.
 template <typename T>
 void launch_jacobi(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u,
-                   const T *rhs, T *out);
+                   const T *rhs, T *out, bool zero_u = false);
 
 // finest-grid fast paths (mg_jacobi_fast.hip); launch_jacobi / launch_residual pick them
 // automatically when fast_path_ok<T>(g)
@@ -21,7 +23,10 @@ template <typename T> bool fast_path_ok(const Geom &g);
 template <typename T> int fast_partials_capacity(const Geom &g);
 template <typename T>
 void launch_jacobi_fast(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u,
-                        const T *rhs, T *out);
+                        const T *rhs, T *out, bool zero_u);
+// out-of-place colour half-sweep (the other colour is copied): red u->tmp, black tmp->u
+template <typename T>
+void launch_rb_fast(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, const T *u, const T *rhs, T *out);
 template <typename T>
 int launch_residual_fast(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs,
                          T *r, double *d_partials, bool want_norm);

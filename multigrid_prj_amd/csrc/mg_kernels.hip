@@ -615,9 +615,9 @@ int reduce_partials_capacity(const Geom &g)
 
 template <typename T>
 void launch_jacobi(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u,
-                   const T *rhs, T *out)
+                   const T *rhs, T *out, bool zero_u)
 {
-    if (fast_path_ok<T>(g)) { launch_jacobi_fast<T>(s, g, c, omega, u, rhs, out); return; }
+    if (fast_path_ok<T>(g)) { launch_jacobi_fast<T>(s, g, c, omega, u, rhs, out, zero_u); return; }
     dim3 gr = grid_for(g.nx, g.ny, g.nz), bl(BX, BY, 1);
     const bool damped = (omega != (T)1);
     if (g.dim == 3) {
@@ -753,7 +753,7 @@ void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega
 
 #define MG_INSTANTIATE(T)                                                                          \
     template void launch_jacobi<T>(hipStream_t, const Geom &, const Coef<T> &, T, const T *,       \
-                                   const T *, T *);                                                \
+                                   const T *, T *, bool);                                              \
     template void launch_rbgs_colour<T>(hipStream_t, const Geom &, const Coef<T> &, int, T *,      \
                                         const T *);                                                \
     template void launch_gs_lex<T>(hipStream_t, const Geom &, const Coef<T> &, int, T *, const T *); \

@@ -335,8 +335,16 @@ static Coef<T> coef_of(const Level &L)
     return Coef<T>{(T)L.coef[0], (T)L.coef[1], (T)L.coef[2], (T)L.coef[3]};
 }
 
+// true when the first pre-smoothing sweep of `level` can consume an implicit zero guess
 template <typename T>
-int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar)
+bool Solver::can_skip_zeroing(int level) const
+{
+    return d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre > 0 && level < d_.levels - 1 &&
+           fast_path_ok<T>(lv_[level].g);
+}
+
+template <typename T>
+int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero)
 {
     Level &L = lv_[level];
     Coef<T> c = coef_of<T>(L);
@@ -352,15 +360,23 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar)
     switch (smoother) {
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
-            MG_TRY(exchange(ax, level));
+            const bool zero_now = x_zero && s == 0;
+            if (!zero_now) MG_TRY(exchange(ax, level));
             launch_jacobi<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level),
-                             ptr<T>(MG_ARR_TMP, level));
+                             ptr<T>(MG_ARR_TMP, level), zero_now);
             // the reference swaps the std::vector buffers (solvers.hpp:82); so do we
             std::swap(L.base[ax], L.base[MG_ARR_TMP]);
         }
         break;
     case MG_SMOOTH_RBGS:
         for (int s = 0; s < sweeps; s++) {
+            if (fast_path_ok<T>(L.g)) {  // vectorised, out of place: red x -> tmp, black tmp -> x
+                MG_TRY(exchange(ax, level));
+                launch_rb_fast<T>(stream_, L.g, c, 0, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level));
+                MG_TRY(exchange(MG_ARR_TMP, level));
+                launch_rb_fast<T>(stream_, L.g, c, 1, ptr<T>(MG_ARR_TMP, level), ptr<T>(ar, level), ptr<T>(ax, level));
+                continue;
+            }
             MG_TRY(exchange(ax, level));
             launch_rbgs_colour<T>(stream_, L.g, c, 0, ptr<T>(ax, level), ptr<T>(ar, level));
             MG_TRY(exchange(ax, level));
@@ -587,7 +603,7 @@ int Solver::coarse_full_t()
 // prolong_t), the residual of level T_ is gathered on rank 0, which runs the deeper levels
 // alone and scatters the prolonged correction back.
 template <typename T>
-int Solver::vcycle_rec_t(int l)
+int Solver::vcycle_rec_t(int l, bool u_zero)
 {
     const int L = d_.levels;
     const bool mine = lv_[l].present;
@@ -601,7 +617,7 @@ int Solver::vcycle_rec_t(int l)
         return mine ? coarse_t<T>(l, MG_ARR_U, MG_ARR_RHS) : (int)MG_OK;
     }
     if (mine) {
-        MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS));
+        MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero));
         MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
     }
     if (lv_[l].dist && !lv_[l + 1].dist) {  // l == T_: hand over to rank 0
@@ -611,8 +627,9 @@ int Solver::vcycle_rec_t(int l)
                 launch_restrict_fw<T>(stream_, gfull_, lv_[l + 1].g, fullptr<T>(0), ptr<T>(MG_ARR_RHS, l + 1));
             else
                 launch_inject<T>(stream_, gfull_, lv_[l + 1].g, fullptr<T>(0), ptr<T>(MG_ARR_RHS, l + 1));
-            MG_TRY(zero_array(MG_ARR_U, l + 1));
-            MG_TRY(vcycle_rec_t<T>(l + 1));
+            const bool skip0 = can_skip_zeroing<T>(l + 1);
+            if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
+            MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
             launch_prolong<T>(stream_, lv_[l + 1].g, gfull_, ptr<T>(MG_ARR_U, l + 1), fullptr<T>(1), false);
             MG_HIP(hipGetLastError());
         }
@@ -620,8 +637,9 @@ int Solver::vcycle_rec_t(int l)
         MG_TRY(correct_t<T>(l, MG_ARR_U, MG_ARR_TMP));  // u += P e, bitwise the same as prolong-add
     } else if (mine) {
         MG_TRY(restrict_t<T>(l, d_.restriction, MG_ARR_TMP, MG_ARR_RHS));
-        MG_TRY(zero_array(MG_ARR_U, l + 1));
-        MG_TRY(vcycle_rec_t<T>(l + 1));
+        const bool skip0 = can_skip_zeroing<T>(l + 1);
+        if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
+        MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
         MG_TRY(prolong_t<T>(l + 1, 1, MG_ARR_U, MG_ARR_U));
     }
     if (mine) MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS));

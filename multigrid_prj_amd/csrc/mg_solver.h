@@ -75,7 +75,10 @@ public:
 
 private:
     template <typename T> T *ptr(int which, int level) const;  // local plane 0
-    template <typename T> int smooth_t(int level, int smoother, int sweeps, int ax, int ar);
+    // x_zero: the caller knows x == 0 (fresh coarse-level guess): the first Jacobi sweep of a
+    // fast-path level then skips reading x (and the caller skips the memset)
+    template <typename T> int smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero = false);
+    template <typename T> bool can_skip_zeroing(int level) const;
     template <typename T> int residual_t(int level, int ax, int ar, int arr_r, bool want_norm);
     template <typename T> int sumsq_t(int level, int arr);
     template <typename T> int restrict_t(int fl, int kind, int as, int ad);
@@ -90,7 +93,7 @@ private:
     template <typename T> int coarse_t(int level, int ax, int ar);
     template <typename T> int coarse_ex_t(int level, int ax, int ar, int smoother, int maxit, double tol, int fixed);
     template <typename T> int cycle_enqueue_t();
-    template <typename T> int vcycle_rec_t(int l);
+    template <typename T> int vcycle_rec_t(int l, bool u_zero = false);
     int cycle_enqueue();
     bool check_arr(int which, int level, const char *fn) const;
     size_t esize() const { return d_.dtype == MG_F64 ? 8 : 4; }

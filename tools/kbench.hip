@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -237,6 +238,158 @@ __global__ __launch_bounds__(64 * BW) void k_zm(Geom g, Coef<double> c, double o
     }
 }
 
+
+// ------------------------------------------------------------------ fused double sweep
+// out = J(J(u)): two damped-Jacobi sweeps in ONE pass over HBM (temporal blocking).
+// Workgroup = TPR threads = one full grid row (TPR*2 doubles + the odd tail column) x TYO
+// output rows, marching ZC planes. Per step p: (1) every thread computes the first sweep
+// v(p) on TYO+2 rows (overlapped tiling in y) from u planes p-1,p,p+1 held in registers;
+// (2) it computes the second sweep on plane q = p-1 of its TYO rows: z-neighbours v(q-1),
+// v(q+1) are its own registers, x/y-neighbours of v(q) come from an LDS plane written in the
+// previous step; (3) it publishes v(p) to the other LDS slot; one barrier.
+template <int TPR, int TYO, int ZC, bool DAMPED>
+__global__ __launch_bounds__(TPR) void k_j2(Geom g, Coef<double> c, double omega, const double *__restrict__ u,
+                                            const double *__restrict__ rhs, double *__restrict__ out, int nby, int nbz)
+{
+    constexpr int TYV = TYO + 2;
+    constexpr int LP = TPR * 2 + 4;  // LDS row pitch (doubles): 2 pad | row | tail | pad
+    __shared__ double lds[2][TYV][LP];
+    int bid = blockIdx.x;
+    const int nblocks = nby * nbz;
+    {
+        int per = (nblocks + 7) >> 3;
+        bid = (bid & 7) * per + (bid >> 3);
+        if (bid >= nblocks) return;
+    }
+    const int by = bid % nby, bz = bid / nby;
+    const int t = threadIdx.x, lane = t & 63;
+    const int x0 = 2 * t;
+    const bool xin = x0 + 1 < g.nx;                 // full pair inside the row
+    const int x0c = min(x0, g.pitch - 2);
+    const bool tail = (g.nx & 1) && (x0 + 2 == g.nx - 1);
+    const int y0 = by * TYO;                        // first output row; v rows y0-1 .. y0+TYO
+    const int z0 = bz * ZC, z1 = min(z0 + ZC, g.nz);
+    long long ro[TYV];  bool ybnd[TYV];
+#pragma unroll
+    for (int r = 0; r < TYV; r++) {
+        int y = min(max(y0 - 1 + r, 0), g.ny - 1);
+        ybnd[r] = (y == 0) || (y == g.ny - 1);
+        ro[r] = (long long)y * g.pitch + x0c;
+    }
+    const long long ro_lo = (long long)min(max(y0 - 2, 0), g.ny - 1) * g.pitch + x0c;
+    const long long ro_hi = (long long)min(y0 + TYO + 1, g.ny - 1) * g.pitch + x0c;
+    const bool xb0 = (x0 == 0), xb1 = (x0 + 1 == g.nx - 1);
+    auto plane_of = [&](int p) { return (long long)min(max(p, -1), g.nz) * g.plane; };  // clamp into the allocation
+
+    d2 um[TYV], uc[TYV], up[TYV];
+    d2 vm[TYO], vc[TYO], vp[TYO];   // own-column v(q-1), v(q), v(q+1) of the output rows
+    d2 bq[TYO];                     // rhs of the output rows at plane q
+#pragma unroll
+    for (int r = 0; r < TYV; r++) {
+        um[r] = *(const d2 *)(u + plane_of(z0 - 2) + ro[r]);
+        uc[r] = *(const d2 *)(u + plane_of(z0 - 1) + ro[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < TYO; r++) { vm[r] = d2{0, 0}; vc[r] = d2{0, 0}; bq[r] = d2{0, 0}; }
+
+    for (int p = z0 - 1; p <= z1; p++) {
+        const long long po = plane_of(p);
+        const double *pu = u + po;
+        // planes outside the domain (p = -1 or nz, only at the first/last chunk) are never
+        // evaluated: their v feeds Dirichlet outputs only, and the wave-edge load of row 0 on
+        // plane -1 would fall one element before the allocation
+        const bool pin = (p >= 0) && (p < g.nz);
+        d2 b[TYV], v[TYV];
+        double vtail[TYV];
+#pragma unroll
+        for (int r = 0; r < TYV; r++) {
+            up[r] = *(const d2 *)(u + plane_of(p + 1) + ro[r]);
+            b[r] = d2{0, 0}; v[r] = d2{0, 0}; vtail[r] = 0;
+        }
+        if (pin) {
+#pragma unroll
+            for (int r = 0; r < TYV; r++) b[r] = *(const d2 *)(rhs + po + ro[r]);
+            const d2 hlo = *(const d2 *)(pu + ro_lo);
+            const d2 hhi = *(const d2 *)(pu + ro_hi);
+            const int gzp = g.gz0 + p;
+            const bool zbp = (gzp <= 0) || (gzp >= g.gnz - 1);
+            // ---- (1) first sweep on plane p, TYV rows
+#pragma unroll
+            for (int r = 0; r < TYV; r++) {
+                double el = 0, er = 0;
+                if (lane == 0) el = pu[ro[r] - 1];
+                if (lane == 63) er = pu[ro[r] + 2];
+                const double xm = dpp_from_prev_lane(uc[r].y, el);
+                const double xp = dpp_from_next_lane(uc[r].x, er);
+                const d2 ym = (r > 0) ? uc[r > 0 ? r - 1 : 0] : hlo;
+                const d2 yp = (r < TYV - 1) ? uc[r < TYV - 1 ? r + 1 : 0] : hhi;
+                double s0 = 0, s1 = 0;
+                s0 += c.cz * um[r].x; s1 += c.cz * um[r].y;
+                s0 += c.cy * ym.x;    s1 += c.cy * ym.y;
+                s0 += c.cx * xm;      s1 += c.cx * uc[r].x;
+                s0 += c.cx * uc[r].y; s1 += c.cx * xp;
+                s0 += c.cy * yp.x;    s1 += c.cy * yp.y;
+                s0 += c.cz * up[r].x; s1 += c.cz * up[r].y;
+                double j0 = (b[r].x - s0) / c.cd, j1 = (b[r].y - s1) / c.cd;
+                if (DAMPED) { j0 = uc[r].x + omega * (j0 - uc[r].x); j1 = uc[r].y + omega * (j1 - uc[r].y); }
+                const bool rb = zbp || ybnd[r];
+                v[r].x = (rb || xb0) ? b[r].x : j0;
+                v[r].y = (rb || xb1) ? b[r].y : j1;
+                if (tail) vtail[r] = rhs[po + ro[r] + 2];   // first sweep on the Dirichlet column: v = rhs
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < TYO; r++) vp[r] = v[r + 1];
+        // ---- (2) second sweep on plane q = p-1 of the TYO output rows
+        const int q = p - 1;
+        if (q >= z0 && q < z1) {
+            const int gzq = g.gz0 + q;
+            const bool zbq = (gzq == 0) || (gzq == g.gnz - 1);
+            const int sl = q & 1;
+            const long long qo = (long long)q * g.plane;
+#pragma unroll
+            for (int r = 0; r < TYO; r++) {
+                const int y = y0 + r;
+                if (y < g.ny) {
+                    const int lr = r + 1;
+                    const double xm = lds[sl][lr][2 + x0 - 1], xp = lds[sl][lr][2 + x0 + 2];
+                    const d2 ym = *(const d2 *)&lds[sl][lr - 1][2 + x0];
+                    const d2 yp = *(const d2 *)&lds[sl][lr + 1][2 + x0];
+                    double s0 = 0, s1 = 0;
+                    s0 += c.cz * vm[r].x; s1 += c.cz * vm[r].y;
+                    s0 += c.cy * ym.x;    s1 += c.cy * ym.y;
+                    s0 += c.cx * xm;      s1 += c.cx * vc[r].x;
+                    s0 += c.cx * vc[r].y; s1 += c.cx * xp;
+                    s0 += c.cy * yp.x;    s1 += c.cy * yp.y;
+                    s0 += c.cz * vp[r].x; s1 += c.cz * vp[r].y;
+                    double j0 = (bq[r].x - s0) / c.cd, j1 = (bq[r].y - s1) / c.cd;
+                    if (DAMPED) { j0 = vc[r].x + omega * (j0 - vc[r].x); j1 = vc[r].y + omega * (j1 - vc[r].y); }
+                    const bool rb = zbq || (y == 0) || (y == g.ny - 1);
+                    d2 res;
+                    res.x = (rb || xb0) ? bq[r].x : j0;
+                    res.y = (rb || xb1) ? bq[r].y : j1;
+                    if (xin) __builtin_nontemporal_store(res, (d2 *)(out + qo + ro[lr]));
+                    if (tail) out[qo + ro[lr] + 2] = rhs[qo + ro[lr] + 2];
+                }
+            }
+        }
+        // ---- (3) publish v(p) for the next step's x/y neighbours
+        {
+            const int sl = p & 1;
+#pragma unroll
+            for (int r = 0; r < TYV; r++) {
+                if (xin) *(d2 *)&lds[sl][r][2 + x0] = v[r];
+                if (tail) lds[sl][r][2 + x0 + 2] = vtail[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < TYV; r++) { um[r] = uc[r]; uc[r] = up[r]; }
+#pragma unroll
+        for (int r = 0; r < TYO; r++) { vm[r] = vc[r]; vc[r] = vp[r]; bq[r] = b[r + 1]; }
+    }
+}
+
 // ------------------------------------------------------------------ harness
 __global__ void k_cmp(Geom g, const double *a, const double *b, unsigned long long *bad)
 {
@@ -352,7 +505,7 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL((k_copy3<true>), dim3(256 * 16), dim3(256), 0, C.s, (const d2 *)C.u, (const d2 *)C.rhs, (d2 *)C.out, n2);
     }, false);
 
-    if (!(argc > 3 && (std::string(argv[3]) == "zc" || std::string(argv[3]) == "tail"))) {
+    if (!(argc > 3 && (std::string(argv[3]) == "zc" || std::string(argv[3]) == "tail" || std::string(argv[3]) == "pair" || std::string(argv[3]) == "j2"))) {
         struct { int mode; double bytes; const char *nm; } modes[] = {{0, 24, "2R+1W"}, {1, 16, "1R+1W"}, {2, 16, "2R"}, {3, 8, "1W"}};
         for (auto &m : modes)
             for (int nt = 0; nt < 2; nt++)
@@ -375,6 +528,95 @@ int main(int argc, char **argv)
 #define STREAM_M(U, NTV) do { if (m.mode == 0) STREAM(U, NTV, 0); else if (m.mode == 1) STREAM(U, NTV, 1); else if (m.mode == 2) STREAM(U, NTV, 2); else STREAM(U, NTV, 3); } while (0)
                     if (nt) { STREAM_M(1, true); STREAM_M(4, true); } else { STREAM_M(1, false); STREAM_M(4, false); }
                 }
+    }
+    if (argc > 3 && std::string(argv[3]) == "j2") {
+        // reference: two plain sweeps u -> A -> ref
+        double *A = nullptr;
+        CK(hipMalloc(&A, elems * 8));
+        CK(hipMemset(A, 0, elems * 8));
+        A += g.plane;
+        hipLaunchKernelGGL((k_ref<true>), gr, dim3(64, 4), 0, C.s, g, C.c, C.omega, C.u, C.rhs, A);
+        hipLaunchKernelGGL((k_ref<true>), gr, dim3(64, 4), 0, C.s, g, C.c, C.omega, A, C.rhs, C.ref);
+        CK(hipStreamSynchronize(C.s));
+        C.pts *= 2;  // two sweeps per launch: GB/s printed = sweep-equivalents
+        auto go = [&](auto kern, const char *nm, int tpr, int tyo, int zc) {
+            int nby = (g.ny + tyo - 1) / tyo, nbz = (g.nz + zc - 1) / zc;
+            int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
+            run(C, nm, [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(tpr), 0, C.s, g, C.c, C.omega, C.u, C.rhs, C.out, nby, nbz); });
+        };
+        for (int rep = 0; rep < 2; rep++) {
+            go(k_j2<256, 1, 8, true>, "j2 TPR=256 TYO=1 ZC=8", 256, 1, 8);
+            go(k_j2<256, 1, 16, true>, "j2 TPR=256 TYO=1 ZC=16", 256, 1, 16);
+            go(k_j2<256, 2, 8, true>, "j2 TPR=256 TYO=2 ZC=8", 256, 2, 8);
+            go(k_j2<256, 2, 12, true>, "j2 TPR=256 TYO=2 ZC=12", 256, 2, 12);
+            go(k_j2<256, 2, 24, true>, "j2 TPR=256 TYO=2 ZC=24", 256, 2, 24);
+            go(k_j2<256, 3, 12, true>, "j2 TPR=256 TYO=3 ZC=12", 256, 3, 12);
+            go(k_j2<256, 3, 16, true>, "j2 TPR=256 TYO=3 ZC=16", 256, 3, 16);
+            go(k_j2<256, 3, 24, true>, "j2 TPR=256 TYO=3 ZC=24", 256, 3, 24);
+            go(k_j2<256, 4, 8, true>, "j2 TPR=256 TYO=4 ZC=8", 256, 4, 8);
+            go(k_j2<256, 4, 16, true>, "j2 TPR=256 TYO=4 ZC=16", 256, 4, 16);
+            go(k_j2<256, 4, 32, true>, "j2 TPR=256 TYO=4 ZC=32", 256, 4, 32);
+            go(k_j2<256, 4, 64, true>, "j2 TPR=256 TYO=4 ZC=64", 256, 4, 64);
+            go(k_j2<256, 2, 16, true>, "j2 TPR=256 TYO=2 ZC=16", 256, 2, 16);
+            go(k_j2<256, 2, 32, true>, "j2 TPR=256 TYO=2 ZC=32", 256, 2, 32);
+        }
+        return 0;
+    }
+    if (argc > 3 && std::string(argv[3]) == "pair") {
+        // Two consecutive sweeps u -> A -> B.  "full": two whole-grid launches.  "chunk CH":
+        // skewed z-chunk order S1(c), S2(c-1) so S2 reads A and rhs while they are still in the
+        // Infinity Cache. Both orders produce identical bits (checked against the full result).
+        auto launch_sub = [&](auto kern, const double *src, double *dst, int c0, int c1) {
+            Geom gs = g; gs.nz = c1 - c0; gs.gz0 = c0;
+            int npairs = gs.nx >> 1;
+            int nbx = (npairs + 63) / 64, nby = (gs.ny + 7) / 8, nbz = (gs.nz + 2) / 3;
+            int nblocks = nbx * nby * nbz, grid = ((nblocks + 7) / 8) * 8;
+            long long off = (long long)c0 * g.plane;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, C.s, gs, C.c, C.omega, src + off, C.rhs + off, dst + off, nbx, nby, nbz);
+        };
+        double *A = C.out, *B = C.ref;
+        double *Bref = nullptr;
+        CK(hipMalloc(&Bref, elems * 8));
+        Bref += g.plane;
+        auto k_nt = k_zm<2, 4, 3, 1, 2, true, true, 3>;
+        auto k_plain = k_zm<2, 4, 3, 1, 0, true, true, 3>;
+        auto k_st = k_zm<2, 4, 3, 1, 1, true, true, 3>;
+        launch_sub(k_nt, C.u, A, 0, g.nz); launch_sub(k_nt, A, Bref, 0, g.nz);
+        CK(hipStreamSynchronize(C.s));
+        auto timeit = [&](const char *name, auto fn) {
+            CK(hipMemsetAsync(B - g.plane, 0xff, elems * 8, C.s));
+            fn(); fn();
+            CK(hipMemsetAsync(C.bad, 0, 8, C.s));
+            hipLaunchKernelGGL(k_cmp, gr, dim3(64, 4), 0, C.s, g, B, Bref, C.bad);
+            unsigned long long bad = 0;
+            CK(hipMemcpyAsync(&bad, C.bad, 8, hipMemcpyDeviceToHost, C.s));
+            CK(hipStreamSynchronize(C.s));
+            CK(hipEventRecord(C.e0, C.s));
+            for (int i = 0; i < C.reps; i++) fn();
+            CK(hipEventRecord(C.e1, C.s));
+            CK(hipEventSynchronize(C.e1));
+            float ms = 0; CK(hipEventElapsedTime(&ms, C.e0, C.e1)); ms /= C.reps;
+            printf("%-44s %8.4f ms per PAIR  %8.1f GB/s/sweep-equivalent (%5.1f%%)  %s\n", name, ms, 2 * C.pts * 24.0 / ms / 1e6,
+                   2 * C.pts * 24.0 / ms / 1e6 / 80.0, bad ? "MISMATCH" : "ok");
+            fflush(stdout);
+        };
+        for (int rep = 0; rep < 2; rep++) {
+            timeit("pair full (2 launches, nt)", [&] { launch_sub(k_nt, C.u, A, 0, g.nz); launch_sub(k_nt, A, B, 0, g.nz); });
+            for (int CH : {6, 9, 12, 15, 18, 24, 30, 36, 48, 60}) {
+                char name[96];
+                for (int mode = 0; mode < 2; mode++) {
+                    snprintf(name, sizeof name, "pair chunked CH=%d S1=%s S2=nt", CH, mode ? "ntstore" : "plain");
+                    timeit(name, [&] {
+                        int nch = (g.nz + CH - 1) / CH;
+                        for (int c = 0; c <= nch; c++) {
+                            if (c < nch) { if (mode) launch_sub(k_st, C.u, A, c * CH, std::min(g.nz, (c + 1) * CH)); else launch_sub(k_plain, C.u, A, c * CH, std::min(g.nz, (c + 1) * CH)); }
+                            if (c > 0) launch_sub(k_nt, A, B, (c - 1) * CH, std::min(g.nz, c * CH));
+                        }
+                    });
+                }
+            }
+        }
+        return 0;
     }
     if (argc > 3 && std::string(argv[3]) == "tail") {
         for (int rep = 0; rep < 2; rep++) {
