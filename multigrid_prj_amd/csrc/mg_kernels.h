@@ -36,6 +36,12 @@ template <typename T> bool prolong_fast_ok(const Geom &gc, const Geom &gf);
 template <typename T>
 void launch_prolong_fast(hipStream_t s, const Geom &gc, const Geom &gf, const T *coarse, T *fine, bool add);
 
+// fused residual + full-weighting restriction (non-distributed 3-D levels): coarse = R (rhs - A u)
+template <typename T> bool resid_restrict_fast_ok(const Geom &gf, const Geom &gc);
+template <typename T>
+void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, const Coef<T> &c, const T *u,
+                              const T *rhs, T *coarse);
+
 // one colour half-sweep of red-black Gauss-Seidel, in place
 template <typename T>
 void launch_rbgs_colour(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u,

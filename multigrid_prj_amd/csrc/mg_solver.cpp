@@ -616,9 +616,12 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         }
         return mine ? coarse_t<T>(l, MG_ARR_U, MG_ARR_RHS) : (int)MG_OK;
     }
+    // fused residual + full weighting when both levels live whole on this rank
+    const bool fuse_rr = mine && d_.restriction == MG_RESTRICT_FULLW && !lv_[l].dist && lv_[l + 1].present &&
+                         resid_restrict_fast_ok<T>(lv_[l].g, lv_[l + 1].g);
     if (mine) {
         MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero));
-        MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
+        if (!fuse_rr) MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
     }
     if (lv_[l].dist && !lv_[l + 1].dist) {  // l == T_: hand over to rank 0
         MG_TRY(gather_T(MG_ARR_TMP, 0));
@@ -636,7 +639,13 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         MG_TRY(scatter_T(1, MG_ARR_TMP));
         MG_TRY(correct_t<T>(l, MG_ARR_U, MG_ARR_TMP));  // u += P e, bitwise the same as prolong-add
     } else if (mine) {
-        MG_TRY(restrict_t<T>(l, d_.restriction, MG_ARR_TMP, MG_ARR_RHS));
+        if (fuse_rr) {
+            launch_resid_restrict_fw<T>(stream_, lv_[l].g, lv_[l + 1].g, coef_of<T>(lv_[l]), ptr<T>(MG_ARR_U, l),
+                                        ptr<T>(MG_ARR_RHS, l), ptr<T>(MG_ARR_RHS, l + 1));
+            MG_HIP(hipGetLastError());
+        } else {
+            MG_TRY(restrict_t<T>(l, d_.restriction, MG_ARR_TMP, MG_ARR_RHS));
+        }
         const bool skip0 = can_skip_zeroing<T>(l + 1);
         if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
         MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
