@@ -40,12 +40,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=513, help="nodes per side (513 = nominal 512^3)")
+    ap.add_argument("--grid", dest="n", type=int, default=513, help="nodes per side (513 = nominal 512^3)")
     ap.add_argument("--levels", type=int, default=6)
     ap.add_argument("--smoother", choices=["jacobi", "rbgs"], default="jacobi")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cycles", type=int, default=1, help="oracle V-cycles timed for cpu_baseline")
+    ap.add_argument("--transport", choices=["rccl", "gloo"], default="rccl",
+                    help="N>1 halo transport: rccl = GPU-to-GPU over xGMI (one GPU per rank, the real thing); "
+                         "gloo = rehearsal through host memory, ranks may share a GPU (numbers meaningless)")
+    ap.add_argument("--dist-min-n", type=int, default=0, help="mg_desc.dist_min_n (0 = library default)")
     return ap.parse_args()
 
 
@@ -56,7 +60,7 @@ def workload_desc(mod, a):
         smoother=mod.SMOOTH_JACOBI if a.smoother == "jacobi" else mod.SMOOTH_RBGS,
         omega=6.0 / 7.0 if a.smoother == "jacobi" else 1.0, nu_pre=2, nu_post=2,
         restriction=mod.RESTRICT_FULLW, coarse_mode=mod.COARSE_TOL, coarse_maxit=2000, coarse_tol=0.1,
-        outer_pre_gs=0)
+        outer_pre_gs=0, dist_min_n=a.dist_min_n)
 
 
 def hash_rhs(n, dtype, z0=0, nz=None, seed=12345):
@@ -94,18 +98,26 @@ def main():
 
     dist = None
     comm_id = None
+    host_comm = None
+    device = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        ids = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm_id = ids[0]
+        if a.transport == "rccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            ids = [capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm_id = ids[0]
+        else:
+            from multigrid_prj_amd.dist import torch_host_comm
+            device = local_rank % max(capi.device_count(), 1)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            host_comm = torch_host_comm()
 
     desc = workload_desc(capi, a)
-    s = capi.Solver(desc, device=local_rank, rank=rank, nranks=world, comm_id=comm_id)
+    s = capi.Solver(desc, device=device, rank=rank, nranks=world, comm_id=comm_id, host_comm=host_comm)
     z0, nz, first_gathered = capi.plan_slab(desc, world, rank, 0)
     npdt = np.float64 if a.dtype == "f64" else np.float32
     s.set_rhs(hash_rhs(a.n, npdt, z0, nz))
@@ -116,7 +128,8 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if a.transport == "rccl":
+                torch.cuda.synchronize()
 
     # warmup (untimed)
     s.cycle_async(a.warmup)
@@ -125,14 +138,13 @@ def main():
     s.profile_begin()
     t0 = time.perf_counter()
     s.cycle_async(a.steps)
-    s.sync()
+    barrier()
     t1 = time.perf_counter()
     sm_ms, sm_sweeps = s.profile_end()
     elapsed = t1 - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if a.transport == "rccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -150,14 +162,14 @@ def main():
     hist, _ = s.solve(0.0, 4)
 
     out = {
-        "metric": "V-cycles/sec (3D Poisson 513^3 V(2,2)) + finest-grid smoother GB/s vs HBM roofline",
+        "metric": f"V-cycles/sec (3D Poisson {a.n}^3 V(2,2)) + finest-grid smoother GB/s vs HBM roofline",
         "value": cycles_per_s, "unit": "V-cycles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"3D Poisson {a.n}^3 nodes (nominal {a.n - 1}^3), {a.levels}-level V(2,2), "
                                f"{a.smoother}{' omega=6/7' if a.smoother == 'jacobi' else ''}, full-weighting, "
                                f"coarse {((a.n - 1) >> (a.levels - 1)) + 1}^3 iterated to rel. residual 0.1, {a.dtype}",
-                   "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
+                   "parallelism": (f"z-slab x{world}" + ("" if a.transport == "rccl" else " (gloo rehearsal)")) if world > 1 else "single GPU",
                    "first_gathered_level": first_gathered},
         "roofline": {"bound": "hbm", "kernel": f"finest-grid {a.smoother} sweep ({a.n}^3)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
