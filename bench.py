@@ -96,6 +96,12 @@ def main():
 
     from multigrid_prj_amd import capi
 
+    if world > 1:
+        # a communication problem must end the run, not hang the node: every rank aborts
+        # itself if the whole benchmark has not finished in time
+        import signal
+        signal.alarm(900)
+
     dist = None
     comm_id = None
     host_comm = None

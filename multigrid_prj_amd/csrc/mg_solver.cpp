@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "mg_kernels.h"
@@ -120,6 +121,9 @@ Solver::~Solver()
             if (b) (void)hipFree(b);
     for (auto &f : full_) if (f) (void)hipFree(f);
     delete comm_;
+    if (ev_ready_) (void)hipEventDestroy(ev_ready_);
+    if (ev_halo_) (void)hipEventDestroy(ev_halo_);
+    if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
     if (d_partials_) (void)hipFree(d_partials_);
     if (d_scal_) (void)hipFree(d_scal_);
     if (d_coarse_) (void)hipFree(d_coarse_);
@@ -144,6 +148,13 @@ int Solver::init()
     MG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     MG_HIP(hipEventCreate(&ev0_));
     MG_HIP(hipEventCreate(&ev1_));
+    if (nranks_ > 1) {
+        MG_HIP(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+        MG_HIP(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
+        MG_HIP(hipEventCreateWithFlags(&ev_halo_, hipEventDisableTiming));
+        const char *ov = getenv("MG_OVERLAP");
+        overlap_ = !(ov && ov[0] == '0');
+    }
 
     const int epl = (int)(128 / esize());  // elements per 128-byte line
     lv_.resize(d_.levels);
@@ -279,6 +290,57 @@ int Solver::exchange(int which, int level)
     return rc;
 }
 
+int Solver::exchange_begin(int which, int level)
+{
+    Level &L = lv_[level];
+    const size_t pb = (size_t)L.g.plane * esize();
+    char *b = reinterpret_cast<char *>(L.base[which]);
+    P2POp ops[4];
+    int n = 0;
+    if (rank_ > 0) {
+        ops[n++] = P2POp{rank_ - 1, true, b + pb, pb};
+        ops[n++] = P2POp{rank_ - 1, false, b, pb};
+    }
+    if (rank_ < nranks_ - 1) {
+        ops[n++] = P2POp{rank_ + 1, true, b + (size_t)L.g.nz * pb, pb};
+        ops[n++] = P2POp{rank_ + 1, false, b + (size_t)(L.g.nz + 1) * pb, pb};
+    }
+    MG_HIP(hipEventRecord(ev_ready_, stream_));
+    MG_HIP(hipStreamWaitEvent(comm_stream_, ev_ready_, 0));
+    int rc = comm_->batch(ops, n, comm_stream_);
+    if (rc) { set_last_error("halo exchange failed"); return rc; }
+    MG_HIP(hipEventRecord(ev_halo_, comm_stream_));
+    return MG_OK;
+}
+
+int Solver::exchange_end()
+{
+    MG_HIP(hipStreamWaitEvent(stream_, ev_halo_, 0));
+    return MG_OK;
+}
+
+template <typename F>
+int Solver::overlapped(int level, int arr_x, F &&launch)
+{
+    Level &L = lv_[level];
+    if (!L.dist) { launch(L.g, (long long)0); return MG_OK; }
+    if (!overlap_ || L.g.nz < 4) {
+        MG_TRY(exchange(arr_x, level));
+        launch(L.g, (long long)0);
+        return MG_OK;
+    }
+    MG_TRY(exchange_begin(arr_x, level));
+    Geom gi = L.g;                      // interior planes 1 .. nz-2 never touch a ghost plane
+    gi.nz = L.g.nz - 2; gi.gz0 = L.g.gz0 + 1;
+    launch(gi, L.g.plane);
+    MG_TRY(exchange_end());
+    Geom g0 = L.g; g0.nz = 1;           // first and last owned plane, now that the halo is in
+    launch(g0, (long long)0);
+    Geom g1 = L.g; g1.nz = 1; g1.gz0 = L.g.gz0 + L.g.nz - 1;
+    launch(g1, (long long)(L.g.nz - 1) * L.g.plane);
+    return MG_OK;
+}
+
 int Solver::gather_T(int which, int fullk)
 {
     Level &L = lv_[T_];
@@ -361,9 +423,14 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
             const bool zero_now = x_zero && s == 0;
-            if (!zero_now) MG_TRY(exchange(ax, level));
-            launch_jacobi<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level),
-                             ptr<T>(MG_ARR_TMP, level), zero_now);
+            T *px = ptr<T>(ax, level), *pr = ptr<T>(ar, level), *pt = ptr<T>(MG_ARR_TMP, level);
+            if (zero_now) {
+                launch_jacobi<T>(stream_, L.g, c, (T)d_.omega, px, pr, pt, true);
+            } else {
+                MG_TRY(overlapped(level, ax, [&](const Geom &gs, long long off) {
+                    launch_jacobi<T>(stream_, gs, c, (T)d_.omega, px + off, pr + off, pt + off, false);
+                }));
+            }
             // the reference swaps the std::vector buffers (solvers.hpp:82); so do we
             std::swap(L.base[ax], L.base[MG_ARR_TMP]);
         }
@@ -371,10 +438,13 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
     case MG_SMOOTH_RBGS:
         for (int s = 0; s < sweeps; s++) {
             if (fast_path_ok<T>(L.g)) {  // vectorised, out of place: red x -> tmp, black tmp -> x
-                MG_TRY(exchange(ax, level));
-                launch_rb_fast<T>(stream_, L.g, c, 0, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level));
-                MG_TRY(exchange(MG_ARR_TMP, level));
-                launch_rb_fast<T>(stream_, L.g, c, 1, ptr<T>(MG_ARR_TMP, level), ptr<T>(ar, level), ptr<T>(ax, level));
+                T *px = ptr<T>(ax, level), *pr = ptr<T>(ar, level), *pt = ptr<T>(MG_ARR_TMP, level);
+                MG_TRY(overlapped(level, ax, [&](const Geom &gs, long long off) {
+                    launch_rb_fast<T>(stream_, gs, c, 0, px + off, pr + off, pt + off);
+                }));
+                MG_TRY(overlapped(level, MG_ARR_TMP, [&](const Geom &gs, long long off) {
+                    launch_rb_fast<T>(stream_, gs, c, 1, pt + off, pr + off, px + off);
+                }));
                 continue;
             }
             MG_TRY(exchange(ax, level));
@@ -417,6 +487,15 @@ template <typename T>
 int Solver::residual_t(int level, int ax, int ar, int arr_r, bool want_norm)
 {
     Level &L = lv_[level];
+    if (!want_norm && arr_r >= 0) {  // vector only: the exchange hides behind the interior planes
+        T *px = ptr<T>(ax, level), *pr = ptr<T>(ar, level), *po = ptr<T>(arr_r, level);
+        Coef<T> c = coef_of<T>(L);
+        MG_TRY(overlapped(level, ax, [&](const Geom &gs, long long off) {
+            launch_residual<T>(stream_, gs, c, px + off, pr + off, po + off, d_partials_, (double *)nullptr);
+        }));
+        MG_HIP(hipGetLastError());
+        return MG_OK;
+    }
     MG_TRY(exchange(ax, level));
     launch_residual<T>(stream_, L.g, coef_of<T>(L), ptr<T>(ax, level), ptr<T>(ar, level),
                        arr_r >= 0 ? ptr<T>(arr_r, level) : (T *)nullptr, d_partials_,

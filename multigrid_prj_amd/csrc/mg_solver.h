@@ -85,7 +85,12 @@ private:
     template <typename T> int prolong_t(int cl, int add, int as, int ad);
     template <typename T> int correct_t(int level, int au, int ae);
     template <typename T> int coarse_full_t();  // coarse solve of a still-distributed coarsest level, gathered
-    int exchange(int which, int level);          // ghost planes <-> z-neighbours
+    int exchange(int which, int level);          // ghost planes <-> z-neighbours (on the main stream)
+    int exchange_begin(int which, int level);    // the same on the comm stream, after the main stream's work so far
+    int exchange_end();                          // main stream waits for the halo
+    // Runs a stencil launch over a distributed level with the halo exchange of `arr_x` hidden
+    // behind the interior planes: launch(sub-slab geometry, element offset of its first plane)
+    template <typename F> int overlapped(int level, int arr_x, F &&launch);
     int gather_T(int which, int fullk);          // slabs of level T_ -> full_[fullk] on rank 0
     int scatter_T(int fullk, int which);         // full_[fullk] on rank 0 -> slabs of level T_
     int allreduce(double *dptr, int n);
@@ -113,6 +118,9 @@ private:
     // levels live on rank 0; full_[] are rank 0's gathered copies of level T_
     Comm *comm_ = nullptr;
     int rank_ = 0, nranks_ = 1, T_ = -1;
+    hipStream_t comm_stream_ = nullptr;
+    hipEvent_t ev_ready_ = nullptr, ev_halo_ = nullptr;
+    bool overlap_ = true;  // MG_OVERLAP=0 disables (debugging)
     Geom gfull_{};
     void *full_[3] = {nullptr, nullptr, nullptr};
     std::vector<SlabPlan> planT_;
