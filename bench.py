@@ -50,6 +50,9 @@ def parse():
                     help="N>1 halo transport: rccl = GPU-to-GPU over xGMI (one GPU per rank, the real thing); "
                          "gloo = rehearsal through host memory, ranks may share a GPU (numbers meaningless)")
     ap.add_argument("--dist-min-n", type=int, default=0, help="mg_desc.dist_min_n (0 = library default)")
+    ap.add_argument("--aniso-eps", type=float, default=1.0, help="z-coupling multiplier eps of -(dxx + dyy + eps dzz)")
+    ap.add_argument("--semi", type=int, default=0, help="number k of leading x,y-only coarsenings (mg_desc.semi_xy); "
+                    "BASELINE config 5: --aniso-eps 0.01 --semi 3 --levels 8 --smoother rbgs")
     return ap.parse_args()
 
 
@@ -59,8 +62,10 @@ def workload_desc(mod, a):
         length=1.0, alpha=1.0, cycle=mod.CYCLE_V,
         smoother=mod.SMOOTH_JACOBI if a.smoother == "jacobi" else mod.SMOOTH_RBGS,
         omega=6.0 / 7.0 if a.smoother == "jacobi" else 1.0, nu_pre=2, nu_post=2,
-        restriction=mod.RESTRICT_FULLW, coarse_mode=mod.COARSE_TOL, coarse_maxit=2000, coarse_tol=0.1,
-        outer_pre_gs=0, dist_min_n=a.dist_min_n)
+        restriction=mod.RESTRICT_FULLW,
+        **({} if a.semi else {"coarse_mode": mod.COARSE_TOL, "coarse_maxit": 2000, "coarse_tol": 0.1}),
+        outer_pre_gs=0, dist_min_n=a.dist_min_n, aniso=(1.0, 1.0, a.aniso_eps), semi_xy=a.semi,
+        **({"coarse_mode": mod.COARSE_FIXED, "coarse_maxit": 20} if a.semi else {}))
 
 
 def hash_rhs(n, dtype, z0=0, nz=None, seed=12345):
@@ -174,7 +179,9 @@ def main():
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"3D Poisson {a.n}^3 nodes (nominal {a.n - 1}^3), {a.levels}-level V(2,2), "
                                f"{a.smoother}{' omega=6/7' if a.smoother == 'jacobi' else ''}, full-weighting, "
-                               f"coarse {((a.n - 1) >> (a.levels - 1)) + 1}^3 iterated to rel. residual 0.1, {a.dtype}",
+                               f"{f'eps={a.aniso_eps}, first {a.semi} coarsenings in x,y only, ' if a.semi or a.aniso_eps != 1.0 else ''}"
+                               + (f"20 coarse sweeps, {a.dtype}" if a.semi else
+                                  f"coarse {((a.n - 1) >> (a.levels - 1)) + 1}^3 iterated to rel. residual 0.1, {a.dtype}"),
                    "parallelism": (f"z-slab x{world}" + ("" if a.transport == "rccl" else " (gloo rehearsal)")) if world > 1 else "single GPU",
                    "first_gathered_level": first_gathered},
         "roofline": {"bound": "hbm", "kernel": f"finest-grid {a.smoother} sweep ({a.n}^3)", "achieved": achieved,

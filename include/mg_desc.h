@@ -57,7 +57,12 @@ typedef struct mg_desc {
                              gathered on rank 0 instead of being slab-decomposed.
                              0 = default (257: below that a halo exchange costs more than the
                              sweep it feeds)                                */
-    int32_t reserved_;
+    int32_t semi_xy;      /* 3-D only: number k of leading SEMI-coarsenings. The first k level
+                             transitions coarsen x and y only (levels 0..k keep the finest grid's z
+                             resolution), the remaining ones coarsen all three axes. For
+                             aniso[2] = eps << 1 (strong coupling inside the x-y planes, BASELINE
+                             config 5) choose k ~ log4(1/eps): after k semi-coarsenings the
+                             operator is roughly isotropic again. 0 = standard coarsening.          */
 } mg_desc;
 
 /* Fills *d with the reference defaults for a 2-D run (`Multigrid -n n -ml levels …`). */
@@ -71,7 +76,7 @@ static inline void mg_desc_reference_defaults(mg_desc *d, int n, int levels,
     d->coarse_mode = MG_COARSE_TOL; d->coarse_maxit = 2000; d->outer_pre_gs = 2;
     d->coarse_tol = 1e-1;
     d->aniso[0] = d->aniso[1] = d->aniso[2] = 1.0;
-    d->dist_min_n = 0; d->reserved_ = 0;
+    d->dist_min_n = 0; d->semi_xy = 0;
 }
 
 /* per-cycle statistics returned by mg_cycle / orc_mg_cycle */

@@ -62,6 +62,9 @@ int mg_destroy(mg_handle h);
 
 /* SquareDomain::getWidth() of level l (domain.hpp:82, domain.cpp:9-12) */
 int mg_level_n(mg_handle h, int level, int *n);
+/* number of z-planes this rank holds of level l (1 in 2-D; the local slab when distributed;
+ * with semi-coarsening every level keeps the finest grid's z resolution) */
+int mg_level_nz(mg_handle h, int level, int *nz);
 /* PoissonMatrix coefficients of level l: out = {cx, cy, cz, cd}
  * (linear_system.hpp:17,27-28,37-38) */
 int mg_level_coefficients(mg_handle h, int level, double out[4]);

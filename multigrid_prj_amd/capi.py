@@ -39,7 +39,7 @@ class MgDesc(C.Structure):
         ("coarse_maxit", C.c_int32), ("outer_pre_gs", C.c_int32),
         ("coarse_tol", C.c_double),
         ("aniso", C.c_double * 3),
-        ("dist_min_n", C.c_int32), ("reserved_", C.c_int32),
+        ("dist_min_n", C.c_int32), ("semi_xy", C.c_int32),
     ]
 
 
@@ -53,7 +53,7 @@ class MgCycleStats(C.Structure):
 def make_desc(dim=2, n=17, levels=2, dtype=MG_F64, length=10.0, alpha=1.0,
               cycle=CYCLE_SAWTOOTH, smoother=SMOOTH_JACOBI, omega=1.0, nu_pre=0, nu_post=5,
               restriction=RESTRICT_INJECT, coarse_mode=COARSE_TOL, coarse_maxit=2000,
-              outer_pre_gs=2, coarse_tol=1e-1, aniso=(1.0, 1.0, 1.0), dist_min_n=0) -> MgDesc:
+              outer_pre_gs=2, coarse_tol=1e-1, aniso=(1.0, 1.0, 1.0), dist_min_n=0, semi_xy=0) -> MgDesc:
     """Defaults are the reference program's hard-coded values (include/mg_desc.h)."""
     d = MgDesc()
     d.dim, d.n, d.levels, d.dtype = dim, n, levels, dtype
@@ -64,6 +64,7 @@ def make_desc(dim=2, n=17, levels=2, dtype=MG_F64, length=10.0, alpha=1.0,
     d.coarse_maxit, d.outer_pre_gs, d.coarse_tol = coarse_maxit, outer_pre_gs, coarse_tol
     d.aniso[0], d.aniso[1], d.aniso[2] = aniso
     d.dist_min_n = dist_min_n
+    d.semi_xy = semi_xy
     return d
 
 
@@ -81,7 +82,7 @@ class MgHostComm(C.Structure):
 
 # every symbol include/mg_hip.h declares (tests check the library exports them all)
 EXPORTS = [
-    "mg_last_error", "mg_device_count", "mg_create", "mg_destroy", "mg_level_n",
+    "mg_last_error", "mg_device_count", "mg_create", "mg_destroy", "mg_level_n", "mg_level_nz",
     "mg_level_coefficients", "mg_set_rhs", "mg_set_solution", "mg_get_solution", "mg_set_array",
     "mg_get_array", "mg_zero_array", "mg_smooth", "mg_residual", "mg_sumsq", "mg_restrict",
     "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_coarse_solve_ex", "mg_cycle", "mg_cycle_async", "mg_solve",
@@ -109,6 +110,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.mg_create.argtypes = [C.POINTER(MgDesc), i, C.POINTER(vp)]
     L.mg_destroy.argtypes = [vp]
     L.mg_level_n.argtypes = [vp, i, C.POINTER(i)]
+    L.mg_level_nz.argtypes = [vp, i, C.POINTER(i)]
     L.mg_level_coefficients.argtypes = [vp, i, dp]
     L.mg_set_rhs.argtypes = [vp, vp]
     L.mg_set_solution.argtypes = [vp, vp]
@@ -212,13 +214,13 @@ class Solver:
     def level_n(self, level: int) -> int:
         n = C.c_int(0); _check(self.lib.mg_level_n(self.h, level, C.byref(n))); return n.value
 
+    def level_nz(self, level: int) -> int:
+        n = C.c_int(0); _check(self.lib.mg_level_nz(self.h, level, C.byref(n))); return n.value
+
     def level_shape(self, level: int):
         """Host shape of this rank's part of a level (the local z-slab when distributed)."""
         n = self.level_n(level)
-        if self.nranks > 1:
-            z0, nz, fg = plan_slab(self.d, self.nranks, self.rank, level)
-            return (nz, n, n)
-        return (n,) * self.d.dim
+        return (n, n) if self.d.dim == 2 else (self.level_nz(level), n, n)
 
     def level_coefficients(self, level: int):
         out = (C.c_double * 4)(); _check(self.lib.mg_level_coefficients(self.h, level, out)); return tuple(out)

@@ -82,6 +82,14 @@ int mg_level_n(mg_handle h, int level, int *n)
     return MG_OK;
 }
 
+int mg_level_nz(mg_handle h, int level, int *nz)
+{
+    MG_H(h);
+    if (!nz || level < 0 || level >= h->impl->nlevels()) return bad("mg_level_nz: bad argument");
+    *nz = h->impl->level(level).present ? h->impl->level(level).g.nz : 0;
+    return MG_OK;
+}
+
 int mg_level_coefficients(mg_handle h, int level, double out[4])
 {
     MG_H(h);

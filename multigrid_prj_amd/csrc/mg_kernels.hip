@@ -202,19 +202,21 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const double *__restrict_
 }
 
 // ---------------------------------------------------------------- transfers
+// semi != 0: semi-coarsening, planes map one to one (z is not coarsened)
 template <typename T>
-__global__ __launch_bounds__(BX *BY) void k_inject(Geom gf, Geom gc, const T *__restrict__ fine,
+__global__ __launch_bounds__(BX *BY) void k_inject(Geom gf, Geom gc, int semi, const T *__restrict__ fine,
                                                    T *__restrict__ coarse)
 {
     int x = blockIdx.x * BX + threadIdx.x;
     int y = blockIdx.y * BY + threadIdx.y;
     int z = blockIdx.z;
     if (x >= gc.nx || y >= gc.ny) return;
-    int fz = (gc.dim == 3) ? 2 * (gc.gz0 + z) - gf.gz0 : 0;
+    int fz = (gc.dim == 3) ? (semi ? z : 2 * (gc.gz0 + z) - gf.gz0) : 0;
     coarse[lidx(gc, z, y, x)] = fine[lidx(gf, fz, 2 * y, 2 * x)];
 }
 
-template <typename T, int DIM>
+// WZ: weights along z too (3-D standard coarsening); otherwise 9-point weights per plane
+template <typename T, int DIM, bool WZ>
 __global__ __launch_bounds__(BX *BY) void k_restrict_fw(Geom gf, Geom gc,
                                                         const T *__restrict__ fine,
                                                         T *__restrict__ coarse)
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(BX *BY) void k_restrict_fw(Geom gf, Geom gc,
     int y = blockIdx.y * BY + threadIdx.y;
     int z = blockIdx.z;
     if (x >= gc.nx || y >= gc.ny) return;
-    int fz = (DIM == 3) ? 2 * (gc.gz0 + z) - gf.gz0 : 0;
+    int fz = (DIM == 3) ? (WZ ? 2 * (gc.gz0 + z) - gf.gz0 : z) : 0;
     long long fi = lidx(gf, fz, 2 * y, 2 * x);
     T out;
     if (on_boundary(gc, z, y, x)) {
@@ -232,8 +234,8 @@ __global__ __launch_bounds__(BX *BY) void k_restrict_fw(Geom gf, Geom gc,
         const T q = (T)0.25, hlf = (T)0.5;
         T zacc[3];
 #pragma unroll
-        for (int dz = 0; dz < (DIM == 3 ? 3 : 1); dz++) {
-            long long oz = (DIM == 3) ? (long long)(dz - 1) * gf.plane : 0;
+        for (int dz = 0; dz < (WZ ? 3 : 1); dz++) {
+            long long oz = WZ ? (long long)(dz - 1) * gf.plane : 0;
             T yacc[3];
 #pragma unroll
             for (int dy = 0; dy < 3; dy++) {
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(BX *BY) void k_restrict_fw(Geom gf, Geom gc,
             }
             zacc[dz] = q * yacc[0] + hlf * yacc[1] + q * yacc[2];
         }
-        out = (DIM == 3) ? q * zacc[0] + hlf * zacc[1] + q * zacc[2] : zacc[0];
+        out = WZ ? q * zacc[0] + hlf * zacc[1] + q * zacc[2] : zacc[0];
     }
     coarse[lidx(gc, z, y, x)] = out;
 }
@@ -250,11 +252,13 @@ __global__ __launch_bounds__(BX *BY) void k_restrict_fw(Geom gf, Geom gc,
 // Interpolated value at fine node (zf,yf,xf), built in the reference's phase order
 // (src/multigrid.cpp:3-27; slow axis first, fast axis last) so that every fine node
 // gets bit for bit what the in-place sequential phases produce.
+// DIM == 23: 3-D semi-coarsening (planes map one to one, gzf is then the LOCAL plane index)
 template <typename T, int DIM>
 __device__ __forceinline__ T interp_z(const Geom &gc, const T *__restrict__ c, int gzf, int yc,
                                       int xc)
 {
     if (DIM == 2) return c[lidx(gc, 0, yc, xc)];
+    if (DIM == 23) return c[lidx(gc, gzf, yc, xc)];
     if ((gzf & 1) == 0) return c[lidx(gc, (gzf >> 1) - gc.gz0, yc, xc)];
     int k0 = ((gzf - 1) >> 1) - gc.gz0;
     return (T)0.5 * (c[lidx(gc, k0, yc, xc)] + c[lidx(gc, k0 + 1, yc, xc)]);
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(BX *BY) void k_prolong(Geom gc, Geom gf,
     int y = blockIdx.y * BY + threadIdx.y;
     int z = blockIdx.z;
     if (x >= gf.nx || y >= gf.ny) return;
-    int gzf = gf.gz0 + z;
+    int gzf = (DIM == 23) ? z : gf.gz0 + z;
     T v;
     if ((x & 1) == 0) v = interp_y<T, DIM>(gc, coarse, gzf, y, x >> 1);
     else v = (T)0.5 * (interp_y<T, DIM>(gc, coarse, gzf, y, (x - 1) >> 1) +
@@ -679,19 +683,22 @@ void launch_sumsq(hipStream_t s, const Geom &g, const T *v, double *d_partials, 
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, d_partials, nb, d_sumsq);
 }
 
+static inline bool is_semi(const Geom &gf, const Geom &gc) { return gf.dim == 3 && gf.gnz == gc.gnz && gf.gnz > 1; }
+
 template <typename T>
 void launch_inject(hipStream_t s, const Geom &gf, const Geom &gc, const T *fine, T *coarse)
 {
     dim3 gr = grid_for(gc.nx, gc.ny, gc.nz), bl(BX, BY, 1);
-    hipLaunchKernelGGL((k_inject<T>), gr, bl, 0, s, gf, gc, fine, coarse);
+    hipLaunchKernelGGL((k_inject<T>), gr, bl, 0, s, gf, gc, is_semi(gf, gc) ? 1 : 0, fine, coarse);
 }
 
 template <typename T>
 void launch_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, const T *fine, T *coarse)
 {
     dim3 gr = grid_for(gc.nx, gc.ny, gc.nz), bl(BX, BY, 1);
-    if (gc.dim == 3) hipLaunchKernelGGL((k_restrict_fw<T, 3>), gr, bl, 0, s, gf, gc, fine, coarse);
-    else hipLaunchKernelGGL((k_restrict_fw<T, 2>), gr, bl, 0, s, gf, gc, fine, coarse);
+    if (gc.dim == 3 && is_semi(gf, gc)) hipLaunchKernelGGL((k_restrict_fw<T, 3, false>), gr, bl, 0, s, gf, gc, fine, coarse);
+    else if (gc.dim == 3) hipLaunchKernelGGL((k_restrict_fw<T, 3, true>), gr, bl, 0, s, gf, gc, fine, coarse);
+    else hipLaunchKernelGGL((k_restrict_fw<T, 2, false>), gr, bl, 0, s, gf, gc, fine, coarse);
 }
 
 template <typename T>
@@ -700,7 +707,10 @@ void launch_prolong(hipStream_t s, const Geom &gc, const Geom &gf, const T *coar
 {
     if (prolong_fast_ok<T>(gc, gf)) { launch_prolong_fast<T>(s, gc, gf, coarse, fine, add); return; }
     dim3 gr = grid_for(gf.nx, gf.ny, gf.nz), bl(BX, BY, 1);
-    if (gf.dim == 3) {
+    if (gf.dim == 3 && is_semi(gf, gc)) {
+        if (add) hipLaunchKernelGGL((k_prolong<T, 23, true>), gr, bl, 0, s, gc, gf, coarse, fine);
+        else hipLaunchKernelGGL((k_prolong<T, 23, false>), gr, bl, 0, s, gc, gf, coarse, fine);
+    } else if (gf.dim == 3) {
         if (add) hipLaunchKernelGGL((k_prolong<T, 3, true>), gr, bl, 0, s, gc, gf, coarse, fine);
         else hipLaunchKernelGGL((k_prolong<T, 3, false>), gr, bl, 0, s, gc, gf, coarse, fine);
     } else {

@@ -47,6 +47,8 @@ int validate_desc(const mg_desc *d, std::string *why)
         return fail("negative sweep count");
     for (int a = 0; a < 3; a++)
         if (!(d->aniso[a] > 0)) return fail("aniso multipliers must be positive");
+    if (d->semi_xy < 0 || d->semi_xy > d->levels - 1) return fail("semi_xy must be in 0..levels-1");
+    if (d->semi_xy && d->dim != 3) return fail("semi-coarsening (semi_xy) needs dim == 3");
     return MG_OK;
 }
 
@@ -70,6 +72,21 @@ void level_coefficients(const mg_desc &d, int level, double out[4])
     out[2] = -(d.alpha * d.aniso[2]) / k;
     double s = (d.dim == 3) ? (d.aniso[0] + d.aniso[1] + d.aniso[2]) : (d.aniso[0] + d.aniso[1]);
     out[3] = ((2.0 * s) * d.alpha) / k;
+    if (d.dim == 3 && d.semi_xy) {  // z is coarsened only after the first semi_xy transitions
+        int lz = level > d.semi_xy ? level - d.semi_xy : 0;
+        double hz = m_h * (double)(1L << lz);
+        double kz = hz * hz;
+        out[2] = -(d.alpha * d.aniso[2]) / kz;
+        out[3] = 2.0 * ((d.alpha * d.aniso[0]) / k + (d.alpha * d.aniso[1]) / k + (d.alpha * d.aniso[2]) / kz);
+    }
+}
+
+int level_nz(const mg_desc &d, int level)
+{
+    if (d.dim != 3) return 1;
+    int nz = d.n;  // the first semi_xy transitions keep z, the later ones halve it
+    for (int l = d.semi_xy; l < level; l++) nz = (nz + 1) / 2;
+    return nz;
 }
 
 int plan_slab(const mg_desc &d, int nranks, int rank, int level, SlabPlan *out, std::string *why)
@@ -78,30 +95,34 @@ int plan_slab(const mg_desc &d, int nranks, int rank, int level, SlabPlan *out, 
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail("bad rank / nranks");
     if (level < 0 || level >= d.levels) return fail("bad level");
     if (nranks > 1 && d.dim != 3) return fail("domain decomposition needs dim == 3");
-    // Distributed levels 0..Ld-1: every rank keeps >= 2 coarse cells and the level has
-    // >= dist_min_n nodes per side; coarser levels are agglomerated on rank 0.
-    // Level 0 is always distributed (that is what the ranks are for).
-    const int min_n = d.dist_min_n > 0 ? d.dist_min_n : 257;
+    // z-cells of level l: the first semi_xy transitions do not coarsen z
+    auto zshift = [&](int l) { return (d.dim == 3 && l > d.semi_xy) ? l - d.semi_xy : 0; };
+    auto zcells = [&](int l) { return (d.n - 1) >> zshift(l); };
+    // Distributed levels 0..Ld-1: every rank keeps >= 2 z-cells and the level holds at least
+    // dist_min_n^3 points (below that a halo exchange costs more than the sweep it feeds);
+    // coarser levels are agglomerated on rank 0. Level 0 is always distributed.
+    const long long min_n = d.dist_min_n > 0 ? d.dist_min_n : 257;
     int Ld = d.levels;
     if (nranks > 1) {
         Ld = 0;
         for (int l = 0; l < d.levels; l++) {
-            int cells = (d.n - 1) >> l;
-            if (cells >= 2 * nranks && (l == 0 || cells + 1 >= min_n)) Ld = l + 1; else break;
+            long long nl = level_n(d, l);
+            long long pts = nl * nl * (zcells(l) + 1);
+            if (zcells(l) >= 2 * nranks && (l == 0 || pts >= min_n * min_n * min_n)) Ld = l + 1; else break;
         }
         if (Ld == 0) return fail("grid too small for this many ranks");
     }
     out->first_gathered_level = Ld;
-    int n_l = level_n(d, level);
     if (d.dim == 2) { out->z0 = 0; out->nz = 1; return MG_OK; }
     if (level >= Ld) {  // gathered: rank 0 owns everything
         out->z0 = 0;
-        out->nz = (rank == 0) ? n_l : 0;
+        out->nz = (rank == 0) ? level_nz(d, level) : 0;
         return MG_OK;
     }
-    // split the cells of the coarsest distributed level; finer levels inherit it
-    int cellsC = (d.n - 1) >> (Ld - 1);
-    int shift = (Ld - 1) - level;
+    // split the z-cells of the coarsest distributed level; finer levels inherit the split, so a
+    // coarse plane K always lives with the fine plane it coincides with (2K, or K when z is kept)
+    int cellsC = zcells(Ld - 1);
+    int shift = zshift(Ld - 1) - zshift(level);
     long s0 = ((long)cellsC * rank) / nranks, s1 = ((long)cellsC * (rank + 1)) / nranks;
     out->z0 = (int)(s0 << shift);
     out->nz = (int)((s1 - s0) << shift) + ((rank == nranks - 1) ? 1 : 0);
@@ -129,6 +150,7 @@ Solver::~Solver()
     if (d_coarse_) (void)hipFree(d_coarse_);
     if (h_scal_) (void)hipHostFree(h_scal_);
     if (h_coarse_) (void)hipHostFree(h_coarse_);
+    if (h_fixed_) (void)hipHostFree(h_fixed_);
     for (auto &e : prof_ev_) (void)hipEventDestroy(e);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
@@ -163,7 +185,7 @@ int Solver::init()
         Level &L = lv_[l];
         int n = level_n(d_, l);
         L.g.dim = d_.dim;
-        L.g.nx = n; L.g.ny = n; L.g.nz = (d_.dim == 3) ? n : 1;
+        L.g.nx = n; L.g.ny = n; L.g.nz = level_nz(d_, l);
         L.g.pitch = ((n + epl - 1) / epl) * epl;
         L.g.plane = (long long)L.g.ny * L.g.pitch;
         L.g.gz0 = 0; L.g.gnz = L.g.nz;
@@ -213,6 +235,7 @@ int Solver::init()
     MG_HIP(hipMemsetAsync(d_coarse_, 0, sizeof(CoarseOut), stream_));
     MG_HIP(hipHostMalloc((void **)&h_scal_, sizeof(double) * 8));
     MG_HIP(hipHostMalloc((void **)&h_coarse_, sizeof(CoarseOut)));
+    MG_HIP(hipHostMalloc((void **)&h_fixed_, sizeof(CoarseOut)));
     bytes_ += sizeof(double) * ((size_t)max_partials + 8) + sizeof(CoarseOut);
     MG_HIP(hipStreamSynchronize(stream_));
     return MG_OK;
@@ -677,6 +700,29 @@ int Solver::coarse_full_t()
     return MG_OK;
 }
 
+template <typename T>
+int Solver::coarse_level_t(int l, int ax, int ar)
+{
+    Level &L = lv_[l];
+    if (!L.present) return MG_OK;  // this rank holds nothing of the level (gathered on rank 0)
+    const long long pts = (long long)L.g.nx * L.g.ny * L.g.gnz;
+    const bool big = pts > 32768;  // e.g. the 17 x 17 x 513 coarsest grid of a semi-coarsened hierarchy
+    if (big && d_.coarse_mode == MG_COARSE_FIXED) {
+        MG_TRY(smooth_t<T>(l, d_.smoother, d_.coarse_maxit, ax, ar));
+        h_fixed_->iters = d_.coarse_maxit; h_fixed_->flag = 0;
+        h_fixed_->relres = 0; h_fixed_->sumsq_rhs = 0; h_fixed_->sumsq_r = 0;  // not evaluated on this path
+        MG_HIP(hipMemcpyAsync(d_coarse_, h_fixed_, sizeof(CoarseOut), hipMemcpyHostToDevice, stream_));
+        return MG_OK;
+    }
+    if (L.dist) {  // small but distributed (few levels, many ranks): gather, solve on rank 0, scatter
+        MG_TRY(gather_T(ar, 0));
+        MG_TRY(coarse_full_t<T>());
+        MG_TRY(scatter_T(1, ax));
+        return MG_OK;
+    }
+    return coarse_t<T>(l, ax, ar);
+}
+
 // Standard V(nu_pre, nu_post) (extension, BASELINE configs 2-4). Slab-decomposed runs: levels
 // 0..T_ are distributed (halo exchanges happen inside smooth_t / residual_t / restrict_t /
 // prolong_t), the residual of level T_ is gathered on rank 0, which runs the deeper levels
@@ -686,15 +732,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
 {
     const int L = d_.levels;
     const bool mine = lv_[l].present;
-    if (l == L - 1) {
-        if (lv_[l].dist) {
-            MG_TRY(gather_T(MG_ARR_RHS, 0));
-            MG_TRY(coarse_full_t<T>());
-            MG_TRY(scatter_T(1, MG_ARR_U));
-            return MG_OK;
-        }
-        return mine ? coarse_t<T>(l, MG_ARR_U, MG_ARR_RHS) : (int)MG_OK;
-    }
+    if (l == L - 1) return coarse_level_t<T>(l, MG_ARR_U, MG_ARR_RHS);
     // fused residual + full weighting when both levels live whole on this rank
     const bool fuse_rr = mine && d_.restriction == MG_RESTRICT_FULLW && !lv_[l].dist && lv_[l + 1].present &&
                          resid_restrict_fast_ok<T>(lv_[l].g, lv_[l + 1].g);
@@ -760,14 +798,8 @@ int Solver::cycle_enqueue_t()
     }
     const int rhsL = (L == 1) ? MG_ARR_RES : MG_ARR_RHS;
     // :128-131 coarse solve from err == 0
-    if (lv_[L - 1].dist) {
-        MG_TRY(gather_T(rhsL, 0));
-        MG_TRY(coarse_full_t<T>());
-        MG_TRY(scatter_T(1, MG_ARR_E));
-    } else if (lv_[L - 1].present) {
-        MG_TRY(zero_array(MG_ARR_E, L - 1));
-        MG_TRY(coarse_t<T>(L - 1, MG_ARR_E, rhsL));
-    }
+    if (lv_[L - 1].present) MG_TRY(zero_array(MG_ARR_E, L - 1));
+    MG_TRY(coarse_level_t<T>(L - 1, MG_ARR_E, rhsL));
     // :134-139 prolong (overwrite) + nu sweeps, coarse to fine
     for (int l = L - 2; l >= 0; l--) {
         if (lv_[l].dist && !lv_[l + 1].dist) {

@@ -18,6 +18,7 @@ void set_last_error(const std::string &msg);
 const std::string &last_error();
 int validate_desc(const mg_desc *d, std::string *why);
 int level_n(const mg_desc &d, int level);
+int level_nz(const mg_desc &d, int level);  // planes of a level (== n unless semi-coarsening)
 void level_coefficients(const mg_desc &d, int level, double out[4]);
 
 struct SlabPlan {
@@ -84,7 +85,10 @@ private:
     template <typename T> int restrict_t(int fl, int kind, int as, int ad);
     template <typename T> int prolong_t(int cl, int add, int as, int ad);
     template <typename T> int correct_t(int level, int au, int ae);
-    template <typename T> int coarse_full_t();  // coarse solve of a still-distributed coarsest level, gathered
+    template <typename T> int coarse_full_t();
+    // coarse "solve" of level l: persistent one-workgroup kernel, or -- when the level is too big
+    // for one workgroup and the mode is MG_COARSE_FIXED -- coarse_maxit regular sweeps
+    template <typename T> int coarse_level_t(int l, int ax, int ar);  // coarse solve of a still-distributed coarsest level, gathered
     int exchange(int which, int level);          // ghost planes <-> z-neighbours (on the main stream)
     int exchange_begin(int which, int level);    // the same on the comm stream, after the main stream's work so far
     int exchange_end();                          // main stream waits for the halo
@@ -113,6 +117,7 @@ private:
     CoarseOut *d_coarse_ = nullptr;
     double *h_scal_ = nullptr;      // pinned mirrors
     CoarseOut *h_coarse_ = nullptr;
+    CoarseOut *h_fixed_ = nullptr;  // pinned: stats reported when the coarse level is swept, not solved
     size_t bytes_ = 0;
     // slab decomposition (mg_create_distributed*): levels 0..T_ are distributed, deeper
     // levels live on rank 0; full_[] are rank 0's gathered copies of level T_

@@ -35,6 +35,8 @@ int main(int argc, char **argv)
     if (opt.full_weighting) d.restriction = MG_RESTRICT_FULLW;
     if (opt.coarse_fixed >= 0) { d.coarse_mode = MG_COARSE_FIXED; d.coarse_maxit = opt.coarse_fixed; }
     if (opt.dim == 3) d.outer_pre_gs = 0;
+    d.aniso[2] = opt.eps_z;
+    d.semi_xy = opt.semi;
 
     // right-hand side: g on the boundary, f inside (DataVector)
     std::vector<double> b;

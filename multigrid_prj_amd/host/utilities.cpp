@@ -35,7 +35,7 @@ void usage()
               << "  -smt, you can choose your favourite smoother" << std::endl
               << "  --help, Display this help message" << std::endl
               << "MI355X extensions:" << std::endl
-              << "  -dim 2|3, -cycle saw|v, -omega W, -nu1 K, -nu2 K, -rbgs, -fw, -coarse_fixed K, -fp32, -maxit K" << std::endl;
+              << "  -dim 2|3, -cycle saw|v, -omega W, -nu1 K, -nu2 K, -rbgs, -fw, -coarse_fixed K, -fp32, -maxit K, -eps E, -semi K" << std::endl;
 }
 
 }  // namespace
@@ -95,6 +95,8 @@ void Utils::parse_command_line(int argc, char **argv, Options &o)
         else if (a == "-nu2" && has_value) { o.nu2 = std::atoi(argv[i + 1]); }
         else if (a == "-coarse_fixed" && has_value) { o.coarse_fixed = std::atoi(argv[i + 1]); }
         else if (a == "-maxit" && has_value) { o.maxit = std::atoi(argv[i + 1]); }
+        else if (a == "-eps" && has_value) { o.eps_z = std::atof(argv[i + 1]); }
+        else if (a == "-semi" && has_value) { o.semi = std::atoi(argv[i + 1]); }
         else if (a == "-rbgs") { o.rbgs = true; }
         else if (a == "-fw") { o.full_weighting = true; }
         else if (a == "-fp32") { o.fp32 = true; }

@@ -38,6 +38,8 @@ int orc_validate(const mg_desc *d)
     if (!(d->length > 0) || !(d->alpha > 0)) return -10;
     if (d->coarse_maxit < 0 || d->nu_pre < 0 || d->nu_post < 0 || d->outer_pre_gs < 0) return -11;
     for (int a = 0; a < 3; a++) if (!(d->aniso[a] > 0)) return -12;
+    if (d->semi_xy < 0 || d->semi_xy > d->levels - 1) return -13;
+    if (d->semi_xy && d->dim != 3) return -13;
     return 0;
 }
 
@@ -46,6 +48,14 @@ int orc_level_n(const mg_desc *d, int level)
     int n = d->n;
     for (int l = 0; l < level; l++) n = (n + 1) / 2; /* src/domain.cpp:9-12 */
     return n;
+}
+
+int orc_level_nz(const mg_desc *d, int level)
+{
+    if (d->dim != 3) return 1;
+    int nz = d->n;   /* the first semi_xy transitions keep z, the later ones halve it */
+    for (int l = d->semi_xy; l < level; l++) nz = (nz + 1) / 2;
+    return nz;
 }
 
 void orc_level_coefficients(const mg_desc *d, int level, double out[4])
@@ -60,6 +70,14 @@ void orc_level_coefficients(const mg_desc *d, int level, double out[4])
     out[2] = -(d->alpha * az) / k;
     double s = (d->dim == 3) ? (ax + ay + az) : (ax + ay);
     out[3] = ((2.0 * s) * d->alpha) / k;         /* linear_system.hpp:27-28: 4.*alpha/k */
+    if (d->dim == 3 && d->semi_xy) {
+        /* semi-coarsening (EXTENSION): z is coarsened only after the first semi_xy transitions */
+        int lz = level > d->semi_xy ? level - d->semi_xy : 0;
+        double hz = m_h * (double)(1L << lz);
+        double kz = hz * hz;
+        out[2] = -(d->alpha * az) / kz;
+        out[3] = 2.0 * ((d->alpha * ax) / k + (d->alpha * ay) / k + (d->alpha * az) / kz);
+    }
 }
 
 /* the (f,g) table of src/utilities.cpp:138-147 */
@@ -207,15 +225,15 @@ int orc_mg_solve(orc_mg *m, double tol, int maxit, double *hist, int hist_cap,
 }
 void orc_mg_smooth_fine(orc_mg *m, int smoother, int sweeps)
 {
-    if (m->h64) orc_smooth_f64(smoother, m->d.dim, m->h64->n[0], m->h64->coef[0], m->d.omega, sweeps,
+    if (m->h64) orc_smooth_f64(smoother, m->d.dim, m->h64->n[0], m->h64->nz[0], m->h64->coef[0], m->d.omega, sweeps,
                                m->h64->u[0], m->h64->rhs[0], m->h64->tmp[0]);
-    else orc_smooth_f32(smoother, m->d.dim, m->h32->n[0], m->h32->coef[0], (float)m->d.omega, sweeps,
+    else orc_smooth_f32(smoother, m->d.dim, m->h32->n[0], m->h32->nz[0], m->h32->coef[0], (float)m->d.omega, sweeps,
                         m->h32->u[0], m->h32->rhs[0], m->h32->tmp[0]);
 }
 double orc_mg_residual_fine(orc_mg *m)
 {
-    if (m->h64) return orc_residual_f64(m->d.dim, m->h64->n[0], m->h64->coef[0], m->h64->u[0],
+    if (m->h64) return orc_residual_f64(m->d.dim, m->h64->n[0], m->h64->nz[0], m->h64->coef[0], m->h64->u[0],
                                         m->h64->rhs[0], NULL);
-    return orc_residual_f32(m->d.dim, m->h32->n[0], m->h32->coef[0], m->h32->u[0],
+    return orc_residual_f32(m->d.dim, m->h32->n[0], m->h32->nz[0], m->h32->coef[0], m->h32->u[0],
                             m->h32->rhs[0], NULL);
 }

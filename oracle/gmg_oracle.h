@@ -32,8 +32,9 @@ extern "C" {
 /* 0 if the descriptor is valid, otherwise a negative code (same codes as mg_hip.h). */
 int orc_validate(const mg_desc *d);
 
-/* nodes per side of level l (src/domain.cpp:9-12) */
+/* nodes per side (x, y) of level l (src/domain.cpp:9-12) and its number of planes */
 int orc_level_n(const mg_desc *d, int level);
+int orc_level_nz(const mg_desc *d, int level);
 
 /* out[0..3] = {cx, cy, cz, cd} of level l in double precision
  * (include/linear_system.hpp:17,27-28,37-38; include/domain.hpp:90; src/domain.cpp:5). */
@@ -56,25 +57,27 @@ void orc_exact_3d(int n, double length, double *u);
 typedef struct orc_coef_f64 { double cx, cy, cz, cd; } orc_coef_f64;
 typedef struct orc_coef_f32 { float cx, cy, cz, cd; } orc_coef_f32;
 
+/* every level is (dim, n, nz): n nodes per side in x/y, nz planes (1 in 2-D); transfers take the
+ * COARSE level's (nc, nzc) and `semi` (1 = z not coarsened) */
 #define ORC_DECL_OPS(REAL, SUF)                                                              \
-    void orc_jacobi_##SUF(int dim, int n, orc_coef_##SUF c, REAL omega, const REAL *u,       \
+    void orc_jacobi_##SUF(int dim, int n, int nz, orc_coef_##SUF c, REAL omega, const REAL *u, \
                           const REAL *rhs, REAL *unew);                                      \
-    void orc_gs_lex_##SUF(int dim, int n, orc_coef_##SUF c, REAL *u, const REAL *rhs);       \
-    void orc_rbgs_##SUF(int dim, int n, orc_coef_##SUF c, REAL *u, const REAL *rhs);         \
-    double orc_residual_##SUF(int dim, int n, orc_coef_##SUF c, const REAL *u,               \
+    void orc_gs_lex_##SUF(int dim, int n, int nz, orc_coef_##SUF c, REAL *u, const REAL *rhs); \
+    void orc_rbgs_##SUF(int dim, int n, int nz, orc_coef_##SUF c, REAL *u, const REAL *rhs); \
+    double orc_residual_##SUF(int dim, int n, int nz, orc_coef_##SUF c, const REAL *u,       \
                               const REAL *rhs, REAL *r);                                     \
-    void orc_residual_vec_##SUF(int dim, int n, orc_coef_##SUF c, const REAL *u,             \
+    void orc_residual_vec_##SUF(int dim, int n, int nz, orc_coef_##SUF c, const REAL *u,     \
                                 const REAL *rhs, REAL *r);                                   \
     double orc_sumsq_##SUF(size_t count, const REAL *v);                                     \
-    void orc_inject_##SUF(int dim, int nc, const REAL *fine, REAL *coarse);                  \
-    void orc_restrict_fw_##SUF(int dim, int nc, const REAL *fine, REAL *coarse);             \
-    void orc_prolong_overwrite_##SUF(int dim, int nc, const REAL *coarse, REAL *fine);       \
-    void orc_prolong_add_##SUF(int dim, int nc, const REAL *coarse, REAL *fine,              \
+    void orc_inject_##SUF(int dim, int nc, int nzc, int semi, const REAL *fine, REAL *coarse); \
+    void orc_restrict_fw_##SUF(int dim, int nc, int nzc, int semi, const REAL *fine, REAL *coarse); \
+    void orc_prolong_overwrite_##SUF(int dim, int nc, int nzc, int semi, const REAL *coarse, REAL *fine); \
+    void orc_prolong_add_##SUF(int dim, int nc, int nzc, int semi, const REAL *coarse, REAL *fine, \
                                REAL *scratch);                                               \
     void orc_correct_##SUF(size_t count, REAL *u, REAL *e);                                  \
-    void orc_smooth_##SUF(int smoother, int dim, int n, orc_coef_##SUF c, REAL omega,        \
+    void orc_smooth_##SUF(int smoother, int dim, int n, int nz, orc_coef_##SUF c, REAL omega, \
                           int sweeps, REAL *u, const REAL *rhs, REAL *tmp);                  \
-    int orc_coarse_solve_##SUF(int smoother, int dim, int n, orc_coef_##SUF c, REAL omega,   \
+    int orc_coarse_solve_##SUF(int smoother, int dim, int n, int nz, orc_coef_##SUF c, REAL omega, \
                                REAL *e, const REAL *rhs, REAL *tmp, int maxit, double tol,   \
                                int fixed, int *flag, double *relres);
 ORC_DECL_OPS(double, f64)

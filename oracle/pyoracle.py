@@ -35,7 +35,7 @@ class MgDesc(C.Structure):
         ("coarse_maxit", C.c_int32), ("outer_pre_gs", C.c_int32),
         ("coarse_tol", C.c_double),
         ("aniso", C.c_double * 3),
-        ("dist_min_n", C.c_int32), ("reserved_", C.c_int32),
+        ("dist_min_n", C.c_int32), ("semi_xy", C.c_int32),
     ]
 
 
@@ -49,7 +49,7 @@ class MgCycleStats(C.Structure):
 def make_desc(dim=2, n=17, levels=2, dtype=MG_F64, length=10.0, alpha=1.0,
               cycle=CYCLE_SAWTOOTH, smoother=SMOOTH_JACOBI, omega=1.0, nu_pre=0, nu_post=5,
               restriction=RESTRICT_INJECT, coarse_mode=COARSE_TOL, coarse_maxit=2000,
-              outer_pre_gs=2, coarse_tol=1e-1, aniso=(1.0, 1.0, 1.0), dist_min_n=0) -> MgDesc:
+              outer_pre_gs=2, coarse_tol=1e-1, aniso=(1.0, 1.0, 1.0), dist_min_n=0, semi_xy=0) -> MgDesc:
     """Defaults == the reference program's hard-coded values (include/mg_desc.h)."""
     d = MgDesc()
     d.dim, d.n, d.levels, d.dtype = dim, n, levels, dtype
@@ -60,6 +60,7 @@ def make_desc(dim=2, n=17, levels=2, dtype=MG_F64, length=10.0, alpha=1.0,
     d.coarse_maxit, d.outer_pre_gs, d.coarse_tol = coarse_maxit, outer_pre_gs, coarse_tol
     d.aniso[0], d.aniso[1], d.aniso[2] = aniso
     d.dist_min_n = dist_min_n
+    d.semi_xy = semi_xy
     return d
 
 
@@ -104,26 +105,28 @@ def lib() -> C.CDLL:
         L = C.CDLL(_LIB_PATH)
         L.orc_validate.argtypes = [C.POINTER(MgDesc)]
         L.orc_level_n.argtypes = [C.POINTER(MgDesc), C.c_int]
+        L.orc_level_nz.argtypes = [C.POINTER(MgDesc), C.c_int]
         L.orc_level_coefficients.argtypes = [C.POINTER(MgDesc), C.c_int, C.POINTER(C.c_double)]
         L.orc_fill_rhs_2d.argtypes = [C.c_int, C.c_double, C.c_int, C.c_void_p]
         L.orc_fill_rhs_3d.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_ulonglong, C.c_void_p]
         L.orc_exact_3d.argtypes = [C.c_int, C.c_double, C.c_void_p]
         for suf, coef, real in (("f64", CoefF64, C.c_double), ("f32", CoefF32, C.c_float)):
             vp = C.c_void_p
-            getattr(L, f"orc_jacobi_{suf}").argtypes = [C.c_int, C.c_int, coef, real, vp, vp, vp]
-            getattr(L, f"orc_gs_lex_{suf}").argtypes = [C.c_int, C.c_int, coef, vp, vp]
-            getattr(L, f"orc_rbgs_{suf}").argtypes = [C.c_int, C.c_int, coef, vp, vp]
-            f = getattr(L, f"orc_residual_{suf}"); f.argtypes = [C.c_int, C.c_int, coef, vp, vp, vp]; f.restype = C.c_double
+            ci = C.c_int
+            getattr(L, f"orc_jacobi_{suf}").argtypes = [ci, ci, ci, coef, real, vp, vp, vp]
+            getattr(L, f"orc_gs_lex_{suf}").argtypes = [ci, ci, ci, coef, vp, vp]
+            getattr(L, f"orc_rbgs_{suf}").argtypes = [ci, ci, ci, coef, vp, vp]
+            f = getattr(L, f"orc_residual_{suf}"); f.argtypes = [ci, ci, ci, coef, vp, vp, vp]; f.restype = C.c_double
             f = getattr(L, f"orc_sumsq_{suf}"); f.argtypes = [C.c_size_t, vp]; f.restype = C.c_double
-            getattr(L, f"orc_inject_{suf}").argtypes = [C.c_int, C.c_int, vp, vp]
-            getattr(L, f"orc_restrict_fw_{suf}").argtypes = [C.c_int, C.c_int, vp, vp]
-            getattr(L, f"orc_prolong_overwrite_{suf}").argtypes = [C.c_int, C.c_int, vp, vp]
-            getattr(L, f"orc_prolong_add_{suf}").argtypes = [C.c_int, C.c_int, vp, vp, vp]
+            getattr(L, f"orc_inject_{suf}").argtypes = [ci, ci, ci, ci, vp, vp]
+            getattr(L, f"orc_restrict_fw_{suf}").argtypes = [ci, ci, ci, ci, vp, vp]
+            getattr(L, f"orc_prolong_overwrite_{suf}").argtypes = [ci, ci, ci, ci, vp, vp]
+            getattr(L, f"orc_prolong_add_{suf}").argtypes = [ci, ci, ci, ci, vp, vp, vp]
             getattr(L, f"orc_correct_{suf}").argtypes = [C.c_size_t, vp, vp]
-            getattr(L, f"orc_smooth_{suf}").argtypes = [C.c_int, C.c_int, C.c_int, coef, real, C.c_int, vp, vp, vp]
+            getattr(L, f"orc_smooth_{suf}").argtypes = [ci, ci, ci, ci, coef, real, ci, vp, vp, vp]
             getattr(L, f"orc_coarse_solve_{suf}").argtypes = [
-                C.c_int, C.c_int, C.c_int, coef, real, vp, vp, vp, C.c_int, C.c_double, C.c_int,
-                C.POINTER(C.c_int), C.POINTER(C.c_double)]
+                ci, ci, ci, ci, coef, real, vp, vp, vp, ci, C.c_double, ci,
+                C.POINTER(ci), C.POINTER(C.c_double)]
         L.orc_mg_create.argtypes = [C.POINTER(MgDesc)]; L.orc_mg_create.restype = C.c_void_p
         L.orc_mg_destroy.argtypes = [C.c_void_p]
         for name in ("orc_mg_set_rhs", "orc_mg_set_solution", "orc_mg_get_solution", "orc_mg_get_residual"):
@@ -147,6 +150,15 @@ def _ptr(a: np.ndarray):
 
 def level_n(desc: MgDesc, level: int) -> int:
     return lib().orc_level_n(C.byref(desc), level)
+
+
+def level_nz(desc: MgDesc, level: int) -> int:
+    return lib().orc_level_nz(C.byref(desc), level)
+
+
+def level_shape(desc: MgDesc, level: int):
+    n = level_n(desc, level)
+    return (n, n) if desc.dim == 2 else (level_nz(desc, level), n, n)
 
 
 def level_coef(desc: MgDesc, level: int):
@@ -191,62 +203,85 @@ class Ops:
         return getattr(lib(), f"orc_{name}_{self.suf}")
 
     def _shape(self, level):
-        n = level_n(self.d, level)
-        return (n,) * self.d.dim
+        return level_shape(self.d, level)
 
     def _chk(self, a, level):
         assert a.dtype == self.np and a.flags.c_contiguous and a.shape == self._shape(level), \
             (a.dtype, a.shape, self._shape(level))
 
+    @staticmethod
+    def _nnz(a):
+        """(n, nz) of a level array: n nodes per side in x/y, nz planes (1 in 2-D)"""
+        return a.shape[-1], (a.shape[0] if a.ndim == 3 else 1)
+
     def jacobi(self, level, u, rhs, omega=None):
         self._chk(u, level); self._chk(rhs, level)
         out = np.empty_like(u)
         om = self.d.omega if omega is None else omega
-        self._f("jacobi")(self.d.dim, u.shape[0], coef_struct(self.d, level), self.real(om),
+        n, nz = self._nnz(u)
+        self._f("jacobi")(self.d.dim, n, nz, coef_struct(self.d, level), self.real(om),
                           _ptr(u), _ptr(rhs), _ptr(out))
         return out
 
     def gs_lex(self, level, u, rhs):
         self._chk(u, level); out = u.copy()
-        self._f("gs_lex")(self.d.dim, u.shape[0], coef_struct(self.d, level), _ptr(out), _ptr(rhs))
+        n, nz = self._nnz(u)
+        self._f("gs_lex")(self.d.dim, n, nz, coef_struct(self.d, level), _ptr(out), _ptr(rhs))
         return out
 
     def rbgs(self, level, u, rhs):
         self._chk(u, level); out = u.copy()
-        self._f("rbgs")(self.d.dim, u.shape[0], coef_struct(self.d, level), _ptr(out), _ptr(rhs))
+        n, nz = self._nnz(u)
+        self._f("rbgs")(self.d.dim, n, nz, coef_struct(self.d, level), _ptr(out), _ptr(rhs))
         return out
 
     def residual(self, level, u, rhs):
         self._chk(u, level); r = np.empty_like(u)
-        s = self._f("residual")(self.d.dim, u.shape[0], coef_struct(self.d, level), _ptr(u), _ptr(rhs), _ptr(r))
+        n, nz = self._nnz(u)
+        s = self._f("residual")(self.d.dim, n, nz, coef_struct(self.d, level), _ptr(u), _ptr(rhs), _ptr(r))
         return r, s
 
     def sumsq(self, v):
         v = np.ascontiguousarray(v, self.np)
         return self._f("sumsq")(v.size, _ptr(v))
 
+    def _level_of(self, a):
+        """level whose (n, nz) match the array (transfers need to know whether z is kept)"""
+        n, nz = self._nnz(a)
+        for l in range(self.d.levels):
+            if level_n(self.d, l) == n and (a.ndim == 2 or level_nz(self.d, l) == nz):
+                return l
+        raise ValueError(f"array shape {a.shape} is not a level of this hierarchy")
+
+    def _semi(self, fine_level):
+        return int(self.d.dim == 3 and fine_level < self.d.semi_xy)
+
     def inject(self, fine):
-        nc = (fine.shape[0] + 1) // 2
-        out = np.empty((nc,) * self.d.dim, self.np)
-        self._f("inject")(self.d.dim, nc, _ptr(fine), _ptr(out))
+        l = self._level_of(fine)
+        out = np.empty(self._shape(l + 1), self.np)
+        nc, nzc = self._nnz(out)
+        self._f("inject")(self.d.dim, nc, nzc, self._semi(l), _ptr(fine), _ptr(out))
         return out
 
     def restrict_fw(self, fine):
-        nc = (fine.shape[0] + 1) // 2
-        out = np.empty((nc,) * self.d.dim, self.np)
-        self._f("restrict_fw")(self.d.dim, nc, _ptr(fine), _ptr(out))
+        l = self._level_of(fine)
+        out = np.empty(self._shape(l + 1), self.np)
+        nc, nzc = self._nnz(out)
+        self._f("restrict_fw")(self.d.dim, nc, nzc, self._semi(l), _ptr(fine), _ptr(out))
         return out
 
     def prolong_overwrite(self, coarse, fine_before=None):
-        nc = coarse.shape[0]; nf = 2 * nc - 1
-        out = np.zeros((nf,) * self.d.dim, self.np) if fine_before is None else fine_before.copy()
-        self._f("prolong_overwrite")(self.d.dim, nc, _ptr(coarse), _ptr(out))
+        lc = self._level_of(coarse)
+        nc, nzc = self._nnz(coarse)
+        out = np.zeros(self._shape(lc - 1), self.np) if fine_before is None else fine_before.copy()
+        self._f("prolong_overwrite")(self.d.dim, nc, nzc, self._semi(lc - 1), _ptr(coarse), _ptr(out))
         return out
 
     def prolong_add(self, coarse, fine):
-        nc = coarse.shape[0]
+        lc = self._level_of(coarse)
+        nc, nzc = self._nnz(coarse)
         out = fine.copy(); scratch = np.empty_like(fine)
-        self._f("prolong_add")(self.d.dim, nc, _ptr(coarse), _ptr(out), _ptr(scratch))
+        self._f("prolong_add")(self.d.dim, nc, nzc, self._semi(lc - 1), _ptr(coarse), _ptr(out), _ptr(scratch))
         return out
 
     def correct(self, u, e):
@@ -257,7 +292,8 @@ class Ops:
     def smooth(self, level, smoother, sweeps, u, rhs, omega=None):
         self._chk(u, level); out = u.copy(); tmp = np.empty_like(u)
         om = self.d.omega if omega is None else omega
-        self._f("smooth")(smoother, self.d.dim, u.shape[0], coef_struct(self.d, level), self.real(om),
+        n, nz = self._nnz(u)
+        self._f("smooth")(smoother, self.d.dim, n, nz, coef_struct(self.d, level), self.real(om),
                           sweeps, _ptr(out), _ptr(rhs), _ptr(tmp))
         return out
 
@@ -265,7 +301,8 @@ class Ops:
         self._chk(e, level); out = e.copy(); tmp = np.empty_like(e)
         flag = C.c_int(0); rel = C.c_double(0)
         om = self.d.omega if omega is None else omega
-        its = self._f("coarse_solve")(smoother, self.d.dim, e.shape[0], coef_struct(self.d, level),
+        n, nz = self._nnz(e)
+        its = self._f("coarse_solve")(smoother, self.d.dim, n, nz, coef_struct(self.d, level),
                                       self.real(om), _ptr(out), _ptr(rhs), _ptr(tmp), maxit, tol,
                                       int(fixed), C.byref(flag), C.byref(rel))
         return out, its, flag.value, rel.value

@@ -17,7 +17,7 @@ class SlabVCycle:
         assert desc.dim == 3 and desc.dtype == capi.MG_F64 and desc.cycle == capi.CYCLE_V
         assert desc.smoother == capi.SMOOTH_JACOBI and desc.coarse_mode == capi.COARSE_FIXED
         self.d, self.rank, self.world, self.dist = desc, rank, world, dist
-        self.od = po.make_desc(**{f: getattr(desc, f) for f, _ in po.MgDesc._fields_ if f not in ("aniso", "reserved_")})
+        self.od = po.make_desc(**{f: getattr(desc, f) for f, _ in po.MgDesc._fields_ if f != "aniso"})
         self.ops = po.Ops(self.od)
         self.L = desc.levels
         self.plan = [[capi.plan_slab(desc, world, r, l) for r in range(world)] for l in range(self.L)]

@@ -86,6 +86,16 @@ def test_slab_plan_default_gathers_latency_bound_levels():
     assert capi.plan_slab(d, 2, 0, 0)[2] == 1      # the finest level is always distributed
 
 
+def test_slab_plan_semi_coarsened_levels_share_their_slabs():
+    """semi_xy = 3: levels 0..3 keep the finest z resolution, so they keep the same z-slabs."""
+    d = capi.make_desc(dim=3, n=513, levels=7, semi_xy=3, aniso=(1.0, 1.0, 0.01))
+    for r in range(4):
+        z0, nz, fg = capi.plan_slab(d, 4, r, 0)
+        assert fg >= 2
+        for l in range(1, min(fg, 4)):
+            assert capi.plan_slab(d, 4, r, l)[:2] == (z0, nz)
+
+
 def test_slab_plan_single_rank_and_errors():
     d = capi.make_desc(dim=3, n=65, levels=3)
     assert capi.plan_slab(d, 1, 0, 0) == (0, 65, 3)
