@@ -119,13 +119,32 @@ int plan_slab(const mg_desc &d, int nranks, int rank, int level, SlabPlan *out, 
         out->nz = (rank == 0) ? level_nz(d, level) : 0;
         return MG_OK;
     }
-    // split the z-cells of the coarsest distributed level; finer levels inherit the split, so a
-    // coarse plane K always lives with the fine plane it coincides with (2K, or K when z is kept)
-    int cellsC = zcells(Ld - 1);
-    int shift = zshift(Ld - 1) - zshift(level);
+    // Split the z-cells of the first gathered level (of the coarsest level if none is gathered);
+    // finer levels inherit the split, so a coarse plane K always lives with the fine plane it
+    // coincides with (2K, or K when z is kept) -- including the planes of the first gathered
+    // level each rank restricts into before they are gathered (plan_stage).
+    const int base = (Ld < d.levels) ? Ld : Ld - 1;
+    int cellsC = zcells(base);
+    int shift = zshift(base) - zshift(level);
     long s0 = ((long)cellsC * rank) / nranks, s1 = ((long)cellsC * (rank + 1)) / nranks;
     out->z0 = (int)(s0 << shift);
     out->nz = (int)((s1 - s0) << shift) + ((rank == nranks - 1) ? 1 : 0);
+    return MG_OK;
+}
+
+int plan_stage(const mg_desc &d, int nranks, int rank, SlabPlan *out, std::string *why)
+{
+    SlabPlan p0;
+    int rc = plan_slab(d, nranks, rank, 0, &p0, why);
+    if (rc) return rc;
+    const int S = p0.first_gathered_level;
+    out->first_gathered_level = S;
+    if (S >= d.levels || nranks == 1) { out->z0 = 0; out->nz = 0; return MG_OK; }
+    auto zshift = [&](int l) { return (d.dim == 3 && l > d.semi_xy) ? l - d.semi_xy : 0; };
+    const int cellsC = (d.n - 1) >> zshift(S);
+    long s0 = ((long)cellsC * rank) / nranks, s1 = ((long)cellsC * (rank + 1)) / nranks;
+    out->z0 = (int)s0;
+    out->nz = (int)(s1 - s0) + ((rank == nranks - 1) ? 1 : 0);
     return MG_OK;
 }
 
@@ -141,6 +160,7 @@ Solver::~Solver()
         for (auto &b : L.base)
             if (b) (void)hipFree(b);
     for (auto &f : full_) if (f) (void)hipFree(f);
+    for (auto &b : stage_base_) if (b) (void)hipFree(b);
     delete comm_;
     if (ev_ready_) (void)hipEventDestroy(ev_ready_);
     if (ev_halo_) (void)hipEventDestroy(ev_halo_);
@@ -199,7 +219,7 @@ int Solver::init()
             L.dist = l < p.first_gathered_level;
             L.present = L.dist || rank_ == 0;
             if (L.dist) {
-                if (l == T_ && rank_ == 0) {  // rank 0 keeps full-size copies of the transition level
+                if (l == T_ && rank_ == 0 && T_ == d_.levels - 1) {  // coarsest level still distributed: rank 0 solves it gathered
                     gfull_ = L.g;
                     for (auto &f : full_) {
                         size_t nbytes = (size_t)(gfull_.nz + 2) * (size_t)gfull_.plane * esize();
@@ -214,6 +234,24 @@ int Solver::init()
                     for (int r = 0; r < nranks_; r++) plan_slab(d_, nranks_, r, l, &planT_[r], &why);
                 }
                 L.g.nz = p.nz; L.g.gz0 = p.z0;
+            }
+        }
+        if (nranks_ > 1 && l == T_ + 1 && l < d_.levels) {
+            // staging slab of the first gathered level: the planes that coincide with this rank's
+            // slab of level T_ (restriction target / prolongation source around the gather)
+            std::string why;
+            planS_.resize(nranks_);
+            for (int r = 0; r < nranks_; r++) {
+                int rc = plan_stage(d_, nranks_, r, &planS_[r], &why);
+                if (rc) { set_last_error("mg_create_distributed: " + why); return rc; }
+            }
+            stage_g_ = L.g;
+            stage_g_.nz = planS_[rank_].nz; stage_g_.gz0 = planS_[rank_].z0;
+            for (auto &b : stage_base_) {
+                size_t nbytes = (size_t)(stage_g_.nz + 2) * (size_t)stage_g_.plane * esize();
+                MG_HIP(hipMalloc(&b, nbytes));
+                MG_HIP(hipMemsetAsync(b, 0, nbytes, stream_));
+                bytes_ += nbytes;
             }
         }
         L.alloc_elems = (size_t)(L.g.nz + 2) * (size_t)L.g.plane;
@@ -362,6 +400,50 @@ int Solver::overlapped(int level, int arr_x, F &&launch)
     Geom g1 = L.g; g1.nz = 1; g1.gz0 = L.g.gz0 + L.g.nz - 1;
     launch(g1, (long long)(L.g.nz - 1) * L.g.plane);
     return MG_OK;
+}
+
+int Solver::gather_S(int arr)
+{
+    const Level &L = lv_[T_ + 1];
+    const size_t pb = (size_t)stage_g_.plane * esize();
+    char *sb = reinterpret_cast<char *>(stage_base_[0]);
+    int rc;
+    if (rank_ == 0) {
+        char *f = reinterpret_cast<char *>(L.base[arr]);
+        MG_HIP(hipMemcpyAsync(f + pb, sb + pb, (size_t)stage_g_.nz * pb, hipMemcpyDeviceToDevice, stream_));
+        std::vector<P2POp> ops;
+        for (int r = 1; r < nranks_; r++)
+            ops.push_back(P2POp{r, false, f + (size_t)(1 + planS_[r].z0) * pb, (size_t)planS_[r].nz * pb});
+        rc = comm_->batch(ops.data(), (int)ops.size(), stream_);
+    } else {
+        P2POp op{0, true, sb + pb, (size_t)stage_g_.nz * pb};
+        rc = comm_->batch(&op, 1, stream_);
+    }
+    if (rc) set_last_error("gather to rank 0 failed");
+    return rc;
+}
+
+int Solver::scatter_S(int arr)
+{
+    // every rank receives its planes plus the next one (upper ghost of the prolongation)
+    const Level &L = lv_[T_ + 1];
+    const size_t pb = (size_t)stage_g_.plane * esize();
+    char *sb = reinterpret_cast<char *>(stage_base_[1]);
+    auto planes = [&](int r) { return (size_t)planS_[r].nz + (r < nranks_ - 1 ? 1 : 0); };
+    int rc;
+    if (rank_ == 0) {
+        char *f = reinterpret_cast<char *>(L.base[arr]);
+        MG_HIP(hipMemcpyAsync(sb + pb, f + pb, planes(0) * pb, hipMemcpyDeviceToDevice, stream_));
+        std::vector<P2POp> ops;
+        for (int r = 1; r < nranks_; r++)
+            ops.push_back(P2POp{r, true, f + (size_t)(1 + planS_[r].z0) * pb, planes(r) * pb});
+        rc = comm_->batch(ops.data(), (int)ops.size(), stream_);
+    } else {
+        P2POp op{0, false, sb + pb, planes(rank_) * pb};
+        rc = comm_->batch(&op, 1, stream_);
+    }
+    if (rc) set_last_error("scatter from rank 0 failed");
+    return rc;
 }
 
 int Solver::gather_T(int which, int fullk)
@@ -740,21 +822,23 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero));
         if (!fuse_rr) MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
     }
-    if (lv_[l].dist && !lv_[l + 1].dist) {  // l == T_: hand over to rank 0
-        MG_TRY(gather_T(MG_ARR_TMP, 0));
+    if (lv_[l].dist && !lv_[l + 1].dist) {  // l == T_: restrict locally, gather the coarse rhs on rank 0
+        if (d_.restriction == MG_RESTRICT_FULLW) {
+            MG_TRY(exchange(MG_ARR_TMP, l));
+            launch_restrict_fw<T>(stream_, lv_[l].g, stage_g_, ptr<T>(MG_ARR_TMP, l), stageptr<T>(0));
+        } else {
+            launch_inject<T>(stream_, lv_[l].g, stage_g_, ptr<T>(MG_ARR_TMP, l), stageptr<T>(0));
+        }
+        MG_HIP(hipGetLastError());
+        MG_TRY(gather_S(MG_ARR_RHS));
         if (rank_ == 0) {
-            if (d_.restriction == MG_RESTRICT_FULLW)
-                launch_restrict_fw<T>(stream_, gfull_, lv_[l + 1].g, fullptr<T>(0), ptr<T>(MG_ARR_RHS, l + 1));
-            else
-                launch_inject<T>(stream_, gfull_, lv_[l + 1].g, fullptr<T>(0), ptr<T>(MG_ARR_RHS, l + 1));
             const bool skip0 = can_skip_zeroing<T>(l + 1);
             if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
             MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
-            launch_prolong<T>(stream_, lv_[l + 1].g, gfull_, ptr<T>(MG_ARR_U, l + 1), fullptr<T>(1), false);
-            MG_HIP(hipGetLastError());
         }
-        MG_TRY(scatter_T(1, MG_ARR_TMP));
-        MG_TRY(correct_t<T>(l, MG_ARR_U, MG_ARR_TMP));  // u += P e, bitwise the same as prolong-add
+        MG_TRY(scatter_S(MG_ARR_U));
+        launch_prolong<T>(stream_, stage_g_, lv_[l].g, stageptr<T>(1), ptr<T>(MG_ARR_U, l), true);
+        MG_HIP(hipGetLastError());
     } else if (mine) {
         if (fuse_rr) {
             launch_resid_restrict_fw<T>(stream_, lv_[l].g, lv_[l + 1].g, coef_of<T>(lv_[l]), ptr<T>(MG_ARR_U, l),
@@ -786,11 +870,9 @@ int Solver::cycle_enqueue_t()
     int src = MG_ARR_RES;
     for (int l = 0; l + 1 < L; l++) {
         if (lv_[l].dist && !lv_[l + 1].dist) {
-            MG_TRY(gather_T(src, 0));
-            if (rank_ == 0) {
-                launch_inject<T>(stream_, gfull_, lv_[l + 1].g, fullptr<T>(0), ptr<T>(MG_ARR_RHS, l + 1));
-                MG_HIP(hipGetLastError());
-            }
+            launch_inject<T>(stream_, lv_[l].g, stage_g_, ptr<T>(src, l), stageptr<T>(0));
+            MG_HIP(hipGetLastError());
+            MG_TRY(gather_S(MG_ARR_RHS));
         } else if (lv_[l].present) {
             MG_TRY(restrict_t<T>(l, MG_RESTRICT_INJECT, src, MG_ARR_RHS));
         }
@@ -803,11 +885,9 @@ int Solver::cycle_enqueue_t()
     // :134-139 prolong (overwrite) + nu sweeps, coarse to fine
     for (int l = L - 2; l >= 0; l--) {
         if (lv_[l].dist && !lv_[l + 1].dist) {
-            if (rank_ == 0) {
-                launch_prolong<T>(stream_, lv_[l + 1].g, gfull_, ptr<T>(MG_ARR_E, l + 1), fullptr<T>(1), false);
-                MG_HIP(hipGetLastError());
-            }
-            MG_TRY(scatter_T(1, MG_ARR_E));
+            MG_TRY(scatter_S(MG_ARR_E));
+            launch_prolong<T>(stream_, stage_g_, lv_[l].g, stageptr<T>(1), ptr<T>(MG_ARR_E, l), false);
+            MG_HIP(hipGetLastError());
         } else if (lv_[l].present) {
             MG_TRY(prolong_t<T>(l + 1, 0, MG_ARR_E, MG_ARR_E));
         }

@@ -27,6 +27,10 @@ struct SlabPlan {
 };
 // host-only partition arithmetic (no HIP call), shared by the library and the CPU tests
 int plan_slab(const mg_desc &d, int nranks, int rank, int level, SlabPlan *out, std::string *why);
+// the planes of the FIRST GATHERED level (level == first_gathered_level) that coincide with this
+// rank's slab of the last distributed level: what the rank restricts into / prolongs from before
+// the level is gathered on / after it is scattered from rank 0
+int plan_stage(const mg_desc &d, int nranks, int rank, SlabPlan *out, std::string *why);
 
 constexpr int NUM_ARR = 5;
 
@@ -95,6 +99,9 @@ private:
     // Runs a stencil launch over a distributed level with the halo exchange of `arr_x` hidden
     // behind the interior planes: launch(sub-slab geometry, element offset of its first plane)
     template <typename F> int overlapped(int level, int arr_x, F &&launch);
+    int gather_S(int arr);                       // staging rhs slabs -> lv_[T_+1].base[arr] on rank 0
+    int scatter_S(int arr);                      // lv_[T_+1].base[arr] on rank 0 -> staging u slabs (+ upper ghost)
+    template <typename T> T *stageptr(int k) const { return reinterpret_cast<T *>(stage_base_[k]) + stage_g_.plane; }
     int gather_T(int which, int fullk);          // slabs of level T_ -> full_[fullk] on rank 0
     int scatter_T(int fullk, int which);         // full_[fullk] on rank 0 -> slabs of level T_
     int allreduce(double *dptr, int n);
@@ -129,6 +136,10 @@ private:
     Geom gfull_{};
     void *full_[3] = {nullptr, nullptr, nullptr};
     std::vector<SlabPlan> planT_;
+    // staging slab of the first gathered level (every rank): [0] restricted rhs, [1] correction
+    Geom stage_g_{};
+    void *stage_base_[2] = {nullptr, nullptr};
+    std::vector<SlabPlan> planS_;
     // in-region timing of the finest-grid smoother (mg_profile_begin/end)
     bool profiling_ = false;
     std::vector<hipEvent_t> prof_ev_;
