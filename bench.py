@@ -172,6 +172,7 @@ def main():
     s.zero_array(capi.ARR_U, 0)
     hist, _ = s.solve(0.0, 4)
 
+    traffic, traffic_src = profiled_traffic(a) if world == 1 else (None, None)
     out = {
         "metric": f"V-cycles/sec (3D Poisson {a.n}^3 V(2,2)) + finest-grid smoother GB/s vs HBM roofline",
         "value": cycles_per_s, "unit": "V-cycles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -186,7 +187,7 @@ def main():
                    "first_gathered_level": first_gathered},
         "roofline": {"bound": "hbm", "kernel": f"finest-grid {a.smoother} sweep ({a.n}^3)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "sweep_ms": sweep_ms, "sweeps_timed": sm_sweeps,
+                     "traffic": traffic, "traffic_source": traffic_src, "sweep_ms": sweep_ms, "sweeps_timed": sm_sweeps,
                      "algorithmic_bytes_per_sweep": bytes_per_sweep},
         "smoother_gbps": achieved,
         "residual_drop_per_cycle": float(hist[-1] / hist[-2]) if len(hist) >= 2 and hist[-2] > 0 else None,
@@ -200,6 +201,28 @@ def main():
     s.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def profiled_traffic(a):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
+    this same command (profiles/r01_kernel_summary.csv, made by tools/profile.sh +
+    tools/summarize_prof.py: separate --pmc FETCH_SIZE / WRITE_SIZE passes, read = 2 x FETCH_SIZE
+    x 1024 on gfx950). Counters cannot be collected inside a timed run, so this is not live;
+    None when the workload is not the profiled default."""
+    if not (a.n == 513 and a.dtype == "f64" and a.smoother == "jacobi" and a.levels == 6 and not a.semi):
+        return None, None
+    path = os.path.join(ROOT, "profiles", "r01_kernel_summary.csv")
+    if not os.path.exists(path):
+        return None, None
+    import csv
+    best = None
+    for r in csv.DictReader(open(path)):
+        if r["kernel"].startswith("k_sweep3d<double, 0,") and r["read_MB"] and r["write_MB"]:
+            if best is None or int(r["grid_threads"]) > int(best["grid_threads"]):
+                best = r
+    if best is None:
+        return None, None
+    return (float(best["read_MB"]) + float(best["write_MB"])) * 1e6, "profiles/r01_kernel_summary.csv (rocprofv3 --pmc passes of this command)"
 
 
 def cpu_baseline(a):

@@ -55,6 +55,32 @@ __global__ __launch_bounds__(256) void k_ref(Geom g, Coef<double> c, double omeg
     out[i] = r;
 }
 
+// reference colour half-sweep (out of place): points of `colour` get the GS update, others copy
+__global__ __launch_bounds__(256) void k_ref_rb(Geom g, Coef<double> c, int colour, const double *__restrict__ u,
+                                                const double *__restrict__ rhs, double *__restrict__ out)
+{
+    int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, z = blockIdx.z;
+    if (x >= g.nx || y >= g.ny) return;
+    long long i = (long long)z * g.plane + (long long)y * g.pitch + x;
+    int gz = g.gz0 + z;
+    double r = u[i];
+    if (((x + y + gz) & 1) == colour) {
+        bool bnd = x == 0 || y == 0 || x == g.nx - 1 || y == g.ny - 1 || gz == 0 || gz == g.gnz - 1;
+        r = rhs[i];
+        if (!bnd) {
+            double sum = 0;
+            sum += c.cz * u[i - g.plane];
+            sum += c.cy * u[i - g.pitch];
+            sum += c.cx * u[i - 1];
+            sum += c.cx * u[i + 1];
+            sum += c.cy * u[i + g.pitch];
+            sum += c.cz * u[i + g.plane];
+            r = (rhs[i] - sum) / c.cd;
+        }
+    }
+    out[i] = r;
+}
+
 // ------------------------------------------------------------------ traffic ceiling
 template <bool NT>
 __global__ __launch_bounds__(256) void k_copy3(const d2 *__restrict__ u, const d2 *__restrict__ rhs,
@@ -247,7 +273,7 @@ __global__ __launch_bounds__(64 * BW) void k_zm(Geom g, Coef<double> c, double o
 // (2) it computes the second sweep on plane q = p-1 of its TYO rows: z-neighbours v(q-1),
 // v(q+1) are its own registers, x/y-neighbours of v(q) come from an LDS plane written in the
 // previous step; (3) it publishes v(p) to the other LDS slot; one barrier.
-template <int TPR, int TYO, int ZC, bool DAMPED>
+template <int TPR, int TYO, int ZC, bool DAMPED, bool RB = false>
 __global__ __launch_bounds__(TPR) void k_j2(Geom g, Coef<double> c, double omega, const double *__restrict__ u,
                                             const double *__restrict__ rhs, double *__restrict__ out, int nby, int nbz)
 {
@@ -336,6 +362,13 @@ __global__ __launch_bounds__(TPR) void k_j2(Geom g, Coef<double> c, double omega
                 v[r].x = (rb || xb0) ? b[r].x : j0;
                 v[r].y = (rb || xb1) ? b[r].y : j1;
                 if (tail) vtail[r] = rhs[po + ro[r] + 2];   // first sweep on the Dirichlet column: v = rhs
+                if (RB) {   // red half-sweep: only points with (x+y+z) even change
+                    const int yy = min(max(y0 - 1 + r, 0), g.ny - 1);
+                    const int par = (x0 + yy + gzp) & 1;   // parity of element .x
+                    if (par != 0) v[r].x = uc[r].x;
+                    if (par == 0) v[r].y = uc[r].y;
+                    if (tail && ((x0 + 2 + yy + gzp) & 1) != 0) vtail[r] = pu[ro[r] + 2];
+                }
             }
         }
 #pragma unroll
@@ -368,8 +401,16 @@ __global__ __launch_bounds__(TPR) void k_j2(Geom g, Coef<double> c, double omega
                     d2 res;
                     res.x = (rb || xb0) ? bq[r].x : j0;
                     res.y = (rb || xb1) ? bq[r].y : j1;
+                    double tailres = 0;
+                    if (tail) tailres = rhs[qo + ro[lr] + 2];
+                    if (RB) {   // black half-sweep: only points with (x+y+z) odd change
+                        const int par = (x0 + y + gzq) & 1;
+                        if (par != 1) res.x = vc[r].x;
+                        if (par == 1) res.y = vc[r].y;
+                        if (tail && ((x0 + 2 + y + gzq) & 1) != 1) tailres = lds[sl][lr][2 + x0 + 2];
+                    }
                     if (xin) __builtin_nontemporal_store(res, (d2 *)(out + qo + ro[lr]));
-                    if (tail) out[qo + ro[lr] + 2] = rhs[qo + ro[lr] + 2];
+                    if (tail) out[qo + ro[lr] + 2] = tailres;
                 }
             }
         }
@@ -505,7 +546,7 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL((k_copy3<true>), dim3(256 * 16), dim3(256), 0, C.s, (const d2 *)C.u, (const d2 *)C.rhs, (d2 *)C.out, n2);
     }, false);
 
-    if (!(argc > 3 && (std::string(argv[3]) == "zc" || std::string(argv[3]) == "tail" || std::string(argv[3]) == "pair" || std::string(argv[3]) == "j2"))) {
+    if (!(argc > 3 && (std::string(argv[3]) == "zc" || std::string(argv[3]) == "tail" || std::string(argv[3]) == "pair" || std::string(argv[3]) == "j2" || std::string(argv[3]) == "rb2"))) {
         struct { int mode; double bytes; const char *nm; } modes[] = {{0, 24, "2R+1W"}, {1, 16, "1R+1W"}, {2, 16, "2R"}, {3, 8, "1W"}};
         for (auto &m : modes)
             for (int nt = 0; nt < 2; nt++)
@@ -528,6 +569,33 @@ int main(int argc, char **argv)
 #define STREAM_M(U, NTV) do { if (m.mode == 0) STREAM(U, NTV, 0); else if (m.mode == 1) STREAM(U, NTV, 1); else if (m.mode == 2) STREAM(U, NTV, 2); else STREAM(U, NTV, 3); } while (0)
                     if (nt) { STREAM_M(1, true); STREAM_M(4, true); } else { STREAM_M(1, false); STREAM_M(4, false); }
                 }
+    }
+    if (argc > 3 && std::string(argv[3]) == "rb2") {
+        double *A = nullptr;
+        CK(hipMalloc(&A, elems * 8));
+        CK(hipMemset(A, 0, elems * 8));
+        A += g.plane;
+        hipLaunchKernelGGL(k_ref_rb, gr, dim3(64, 4), 0, C.s, g, C.c, 0, C.u, C.rhs, A);
+        hipLaunchKernelGGL(k_ref_rb, gr, dim3(64, 4), 0, C.s, g, C.c, 1, A, C.rhs, C.ref);
+        CK(hipStreamSynchronize(C.s));
+        auto go = [&](auto kern, const char *nm, int tpr, int tyo, int zc) {
+            int nby = (g.ny + tyo - 1) / tyo, nbz = (g.nz + zc - 1) / zc;
+            int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
+            run(C, nm, [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(tpr), 0, C.s, g, C.c, C.omega, C.u, C.rhs, C.out, nby, nbz); });
+        };
+        for (int rep = 0; rep < 2; rep++) {
+            run(C, "rb unfused reference pair (1 pt/thread)", [&] {
+                hipLaunchKernelGGL(k_ref_rb, gr, dim3(64, 4), 0, C.s, g, C.c, 0, C.u, C.rhs, A);
+                hipLaunchKernelGGL(k_ref_rb, gr, dim3(64, 4), 0, C.s, g, C.c, 1, A, C.rhs, C.out);
+            });
+            go(k_j2<256, 2, 12, false, true>, "rb fused TPR=256 TYO=2 ZC=12", 256, 2, 12);
+            go(k_j2<256, 2, 24, false, true>, "rb fused TPR=256 TYO=2 ZC=24", 256, 2, 24);
+            go(k_j2<256, 3, 16, false, true>, "rb fused TPR=256 TYO=3 ZC=16", 256, 3, 16);
+            go(k_j2<256, 4, 16, false, true>, "rb fused TPR=256 TYO=4 ZC=16", 256, 4, 16);
+            go(k_j2<256, 4, 32, false, true>, "rb fused TPR=256 TYO=4 ZC=32", 256, 4, 32);
+            go(k_j2<256, 6, 24, false, true>, "rb fused TPR=256 TYO=6 ZC=24", 256, 6, 24);
+        }
+        return 0;
     }
     if (argc > 3 && std::string(argv[3]) == "j2") {
         // reference: two plain sweeps u -> A -> ref

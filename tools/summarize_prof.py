@@ -22,11 +22,17 @@ def short(name):
     return name.strip()
 
 
+def newest(pattern):
+    """gpurun merges every call's files into the same local directory: take the latest."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:] if files else []
+
+
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
     os.makedirs(out_dir, exist_ok=True)
-    trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
+    trace = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
     groups = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
         gsz = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
@@ -36,7 +42,7 @@ def main():
     total = sum(sum(d for d, *_ in v) for v in groups.values())
     pmc = {}
     for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-        files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+        files = newest(os.path.join(src, sub, "*", "*_counter_collection.csv"))
         if not files:
             continue
         acc = collections.defaultdict(list)
@@ -77,7 +83,7 @@ def main():
     open(os.path.join(out_dir, f"{tag}_kernel_summary.md"), "w").write("\n".join(lines))
     with open(os.path.join(out_dir, f"{tag}_kernel_summary.csv"), "w", newline="") as fcsv:
         csv.writer(fcsv).writerows(rows_csv)
-    st = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    st = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
     if st:
         open(os.path.join(out_dir, f"{tag}_rocprofv3_kernel_stats.csv"), "w").write(open(st[0]).read())
     print("\n".join(lines))
