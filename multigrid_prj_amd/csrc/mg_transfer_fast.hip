@@ -161,20 +161,22 @@ __device__ __forceinline__ double prev_lane(double v, double edge)
 
 constexpr int ZCC = 4;   // coarse planes per workgroup
 
-// One workgroup = one coarse row J over its whole width: NW waves side by side in x.
-template <typename T, bool NTLOAD>
-__global__ __launch_bounds__(1024) void k_resid_restrict_fw(Geom gf, Geom gc, Coef<T> c, const T *__restrict__ u,
+// One workgroup = CR consecutive coarse rows over their whole width: NW waves side by side in
+// x; each lane evaluates the 2*CR+1 fine residual rows those coarse rows need (neighbouring
+// workgroups recompute the shared odd row: 1.5x residual work for CR = 1, 1.25x for CR = 2).
+template <typename T, bool NTLOAD, int CR>
+__global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coef<T> c, const T *__restrict__ u,
                                                             const T *__restrict__ rhs, T *__restrict__ coarse,
                                                             int nby, int nbz)
 {
-    constexpr int V = PV<T>::V, CV = V / 2;
+    constexpr int V = PV<T>::V, CV = V / 2, NR = 2 * CR + 1;
     typedef typename PV<T>::vec vec;
-    __shared__ T edge[2][16][3];  // [slot][wave][row]: last residual element of each wave
+    __shared__ T edge[2][8][NR];  // [slot][wave][row]: last residual element of each wave
     const int nblocks = nby * nbz;
     const int per = (nblocks + 7) >> 3;
     const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order
     if (bid >= nblocks) return;                                   // whole workgroup
-    const int J = bid % nby, bz = bid / nby;
+    const int J0 = (bid % nby) * CR, bz = bid / nby;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ic0 = CV * (wv * 64 + lane);   // first coarse column of the lane
     const int x0 = 2 * ic0;                  // first fine x
@@ -182,38 +184,41 @@ __global__ __launch_bounds__(1024) void k_resid_restrict_fw(Geom gf, Geom gc, Co
     const bool cin = ic0 + CV - 1 <= gc.nx - 2;      // owns CV real coarse columns (tail column excluded)
     const bool tail_lane = (x0 + V == gf.nx - 1);    // the lane next to the odd last fine column
     const int K0 = bz * ZCC, K1 = min(K0 + ZCC, gc.nz);
-    // fine rows 2J-1, 2J, 2J+1 (clamped rows only ever feed injecting boundary nodes)
-    long long ro[3];
-    bool ybnd[3];
+    // fine rows 2*J0-1 .. 2*J0+2*CR-1 (clamped rows only ever feed injecting boundary nodes)
+    long long ro[NR];
+    bool ybnd[NR];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int y = min(max(2 * J - 1 + r, 0), gf.ny - 1);
+    for (int r = 0; r < NR; r++) {
+        const int y = min(max(2 * J0 - 1 + r, 0), gf.ny - 1);
         ybnd[r] = (y == 0) || (y == gf.ny - 1);
         ro[r] = (long long)y * gf.pitch + x0c;
     }
-    const long long ro_lo = (long long)min(max(2 * J - 2, 0), gf.ny - 1) * gf.pitch + x0c;
-    const long long ro_hi = (long long)min(2 * J + 2, gf.ny - 1) * gf.pitch + x0c;
-    const bool Jbnd = (J == 0) || (J == gc.ny - 1);
+    const long long ro_lo = (long long)min(max(2 * J0 - 2, 0), gf.ny - 1) * gf.pitch + x0c;
+    const long long ro_hi = (long long)min(2 * J0 + 2 * CR, gf.ny - 1) * gf.pitch + x0c;
     const T q = (T)0.25, h = (T)0.5;
 
     const int zs = max(2 * K0 - 1, 0), ze = min(2 * (K1 - 1) + 1, gf.nz - 1);  // all inside the grid
-    vec um[3], uc[3], up[3];
+    vec um[NR], uc[NR], up[NR];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < NR; r++) {
         um[r] = *(const vec *)(u + (long long)(zs - 1) * gf.plane + ro[r]);  // zs-1 >= -1: ghost plane
         uc[r] = *(const vec *)(u + (long long)zs * gf.plane + ro[r]);
     }
-    T ywm[CV], ywc[CV], ctr[CV], ctr_tail = 0;
+    T ywm[CR][CV], ywc[CR][CV], ctr[CR][CV], ctr_tail[CR];
 #pragma unroll
-    for (int m = 0; m < CV; m++) { ywm[m] = 0; ywc[m] = 0; ctr[m] = 0; }
+    for (int j = 0; j < CR; j++) {
+        ctr_tail[j] = 0;
+#pragma unroll
+        for (int m = 0; m < CV; m++) { ywm[j][m] = 0; ywc[j][m] = 0; ctr[j][m] = 0; }
+    }
     int slot = 0;
 
     for (int z = zs; z <= ze; z++) {
         const long long zo = (long long)z * gf.plane;
         const T *pz = u + zo;
-        vec b[3];
+        vec b[NR];
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < NR; r++) {
             up[r] = *(const vec *)(pz + gf.plane + ro[r]);  // z+1 <= nz: ghost plane
             if (NTLOAD) b[r] = __builtin_nontemporal_load((const vec *)(rhs + zo + ro[r]));
             else b[r] = *(const vec *)(rhs + zo + ro[r]);
@@ -221,16 +226,16 @@ __global__ __launch_bounds__(1024) void k_resid_restrict_fw(Geom gf, Geom gc, Co
         const vec hlo = *(const vec *)(pz + ro_lo);
         const vec hhi = *(const vec *)(pz + ro_hi);
         const bool zb = (z == 0) || (z == gf.nz - 1);
-        vec res[3];
+        vec res[NR];
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < NR; r++) {
             T el = 0, er = 0;
             if (lane == 0) el = pz[ro[r] - 1];
             if (lane == 63) er = pz[ro[r] + V];
             const T xm = prev_lane(uc[r][V - 1], el);
             const T xp = next_lane(uc[r][0], er);
             const vec ym = (r == 0) ? hlo : uc[r > 0 ? r - 1 : 0];
-            const vec yp = (r == 2) ? hhi : uc[r < 2 ? r + 1 : 0];
+            const vec yp = (r == NR - 1) ? hhi : uc[r < NR - 1 ? r + 1 : 0];
             const bool rb = zb || ybnd[r];
 #pragma unroll
             for (int e = 0; e < V; e++) {
@@ -251,58 +256,55 @@ __global__ __launch_bounds__(1024) void k_resid_restrict_fw(Geom gf, Geom gc, Co
             if (lane == 63) edge[slot][wv][r] = res[r][V - 1];
         }
         __syncthreads();
-        T yw[CV], rc[CV];
-        {
-            T xw[3][CV];
+        T xw[NR][CV];
 #pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const T from_left_wave = (lane == 0 && wv > 0) ? edge[slot][wv - 1][r] : (T)0;
-                const T rprev = prev_lane(res[r][V - 1], from_left_wave);
-#pragma unroll
-                for (int m = 0; m < CV; m++) {
-                    const T rleft = (m == 0) ? rprev : res[r][2 * m - 1 > 0 ? 2 * m - 1 : 0];
-                    xw[r][m] = q * rleft + h * res[r][2 * m] + q * res[r][2 * m + 1];
-                }
-            }
+        for (int r = 0; r < NR; r++) {
+            const T from_left_wave = (lane == 0 && wv > 0) ? edge[slot][wv - 1][r] : (T)0;
+            const T rprev = prev_lane(res[r][V - 1], from_left_wave);
 #pragma unroll
             for (int m = 0; m < CV; m++) {
-                yw[m] = q * xw[0][m] + h * xw[1][m] + q * xw[2][m];
-                rc[m] = res[1][2 * m];
+                const T rleft = (m == 0) ? rprev : res[r][2 * m - 1 > 0 ? 2 * m - 1 : 0];
+                xw[r][m] = q * rleft + h * res[r][2 * m] + q * res[r][2 * m + 1];
             }
         }
         slot ^= 1;
-        T rtail = 0;
-        if (tail_lane) {  // odd last fine column (Dirichlet): r = rhs - u on the centre row
-            const long long i = zo + (ro[1] - x0c) + gf.nx - 1;
-            rtail = rhs[i] - (T)1 * u[i];
-        }
         int emitK = -1;
-        if (z & 1) {                       // z = 2K+1 closes coarse plane K
-            emitK = (z - 1) >> 1;
-        } else {                           // z = 2K: centre plane
+        if (z & 1) emitK = (z - 1) >> 1;                 // z = 2K+1 closes coarse plane K
+        else if (z == gf.nz - 1) emitK = z >> 1;         // top boundary plane has no z+1: it injects
 #pragma unroll
-            for (int m = 0; m < CV; m++) { ywc[m] = yw[m]; ctr[m] = rc[m]; }
-            ctr_tail = rtail;
-            if (z == gf.nz - 1) emitK = z >> 1;   // top boundary plane has no z+1: it injects
-        }
-        if (emitK >= K0 && emitK < K1) {
-            const bool Kbnd = (emitK == 0) || (emitK == gc.nz - 1);
-            const long long co = (long long)emitK * gc.plane + (long long)J * gc.pitch;
+        for (int j = 0; j < CR; j++) {
+            const int J = J0 + j;
+            T yw[CV];
 #pragma unroll
-            for (int m = 0; m < CV; m++) {
-                const int I = ic0 + m;
-                const bool Ibnd = (I == 0) || (I == gc.nx - 1);
-                const T fw = q * ywm[m] + h * ywc[m] + q * yw[m];
-                if (cin) coarse[co + I] = (Kbnd || Jbnd || Ibnd) ? ctr[m] : fw;
+            for (int m = 0; m < CV; m++) yw[m] = q * xw[2 * j][m] + h * xw[2 * j + 1][m] + q * xw[2 * j + 2][m];
+            if (!(z & 1)) {                              // z = 2K: centre plane
+#pragma unroll
+                for (int m = 0; m < CV; m++) { ywc[j][m] = yw[m]; ctr[j][m] = res[2 * j + 1][2 * m]; }
+                if (tail_lane) {  // odd last fine column (Dirichlet): r = rhs - u on the centre row
+                    const long long i = zo + (ro[2 * j + 1] - x0c) + gf.nx - 1;
+                    ctr_tail[j] = rhs[i] - (T)1 * u[i];
+                }
             }
-            if (tail_lane) coarse[co + gc.nx - 1] = ctr_tail;  // coarse column nc-1 is a boundary node
-        }
-        if (z & 1) {
+            if (emitK >= K0 && emitK < K1 && J < gc.ny) {
+                const bool Kbnd = (emitK == 0) || (emitK == gc.nz - 1);
+                const bool Jbnd = (J == 0) || (J == gc.ny - 1);
+                const long long co = (long long)emitK * gc.plane + (long long)J * gc.pitch;
 #pragma unroll
-            for (int m = 0; m < CV; m++) ywm[m] = yw[m];
+                for (int m = 0; m < CV; m++) {
+                    const int I = ic0 + m;
+                    const bool Ibnd = (I == 0) || (I == gc.nx - 1);
+                    const T fw = q * ywm[j][m] + h * ywc[j][m] + q * yw[m];
+                    if (cin) coarse[co + I] = (Kbnd || Jbnd || Ibnd) ? ctr[j][m] : fw;
+                }
+                if (tail_lane) coarse[co + gc.nx - 1] = ctr_tail[j];  // coarse column nc-1 is a boundary node
+            }
+            if (z & 1) {
+#pragma unroll
+                for (int m = 0; m < CV; m++) ywm[j][m] = yw[m];
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 3; r++) { um[r] = uc[r]; uc[r] = up[r]; }
+        for (int r = 0; r < NR; r++) { um[r] = uc[r]; uc[r] = up[r]; }
     }
 }
 
@@ -344,7 +346,7 @@ bool resid_restrict_fast_ok(const Geom &gf, const Geom &gc)
     constexpr int V = PV<T>::V;
     return gf.dim == 3 && gf.nx == 2 * gc.nx - 1 && gf.ny == 2 * gc.ny - 1 && gf.nz == 2 * gc.nz - 1 &&
            gf.gz0 == 0 && gc.gz0 == 0 && gf.gnz == gf.nz && gc.gnz == gc.nz && gc.nx >= 17 && (gf.nx % V) == 1 &&
-           (gc.nx - 1 + 64 * (V / 2) - 1) / (64 * (V / 2)) <= 16;
+           (gc.nx - 1 + 64 * (V / 2) - 1) / (64 * (V / 2)) <= 8;
 }
 
 template <typename T>
@@ -352,14 +354,15 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
                               const T *rhs, T *coarse)
 {
     constexpr int CV = PV<T>::V / 2;
+    constexpr int CR = 1;                                     // coarse rows per workgroup (2 measured slower: 156 VGPRs)
     const int ncol = gc.nx - 1;                               // coarse columns owned by lanes
-    const int nw = (ncol + 64 * CV - 1) / (64 * CV);          // waves side by side in x (<= 16)
-    const int nby = gc.ny;                                    // one workgroup per coarse row
+    const int nw = (ncol + 64 * CV - 1) / (64 * CV);          // waves side by side in x (<= 8)
+    const int nby = (gc.ny + CR - 1) / CR;
     const int nbz = (gc.nz + ZCC - 1) / ZCC;
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool nt = (size_t)gf.nz * gf.plane * sizeof(T) >= ((size_t)64 << 20);
-    if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
-    else hipLaunchKernelGGL((k_resid_restrict_fw<T, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
+    if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
+    else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
 }
 
 template bool resid_restrict_fast_ok<double>(const Geom &, const Geom &);

@@ -26,6 +26,18 @@ def test_library_exports_every_declared_symbol():
     assert sorted(capi.EXPORTS) == declared
 
 
+def test_headers_are_plain_c(tmp_path):
+    """include/mg_hip.h and mg_desc.h are what a C / cgo / JNI / ctypes binding includes:
+    they must compile as C99 with nothing but the standard headers."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "mg_hip.h"\n'
+                   'int main(void) { mg_desc d; mg_desc_reference_defaults(&d, 17, 2, 10.0, 1.0, MG_SMOOTH_JACOBI);\n'
+                   '  mg_handle h = 0; (void)h; return d.n == 17 ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    "-c", str(src), "-o", str(tmp_path / "abi.o")], check=True)
+
+
 def test_no_cpu_fallback():
     if capi.device_count() > 0:
         pytest.skip("a GPU is present")

@@ -110,6 +110,29 @@ def test_cli_reproduces_the_reference_result_files(fix, args, tmp_path):
     np.testing.assert_allclose(x[1:], xr, rtol=2e-5, atol=1e-8)
 
 
+@pytest.mark.gpu
+def test_cli_extension_flags_3d_vcycle(tmp_path):
+    """-dim 3 -cycle v … : the MI355X extensions of the command line, against the oracle."""
+    from oracle import pyoracle as po
+    exe = mgbuild.build_cli()
+    n = 33
+    rc, out = run_cli(exe, f"-n {n} -a 1 -w 1 -ml 3 -test 0 -smt 1 -dim 3 -cycle v -omega 0.857142857142857 "
+                           f"-nu1 2 -nu2 2 -fw -coarse_fixed 30 -maxit 6".split(), tmp_path)
+    assert rc == 0, out
+    hist = [float(x) for x in open(tmp_path / "MGGS4.txt").read().split()][1:]
+    d = po.make_desc(dim=3, n=n, levels=3, length=1.0, alpha=1.0, cycle=po.CYCLE_V, smoother=po.SMOOTH_JACOBI,
+                     omega=0.857142857142857, nu_pre=2, nu_post=2, restriction=po.RESTRICT_FULLW,
+                     coarse_mode=po.COARSE_FIXED, coarse_maxit=30, outer_pre_gs=0)
+    o = po.Solver(d)
+    b = np.ones((n, n, n)); b[0] = b[-1] = 0; b[:, 0] = b[:, -1] = 0; b[:, :, 0] = b[:, :, -1] = 0  # f = 1, g = 0
+    o.set_rhs(b)
+    href, _ = o.solve(1e-11, 6)
+    np.testing.assert_allclose(hist, href, rtol=2e-5)   # file has 6 significant digits
+    x = np.loadtxt(tmp_path / "x.mtx")
+    assert int(x[0]) == n ** 3
+    np.testing.assert_allclose(x[1:], o.get_solution().ravel(), rtol=2e-5, atol=1e-9)
+
+
 @pytest.fixture(scope="module")
 def mirror_ops():
     return mgbuild.build_mirror_harness(os.path.join(ROOT, "tests", "cpp", "_build", "mirror_ops"))
