@@ -117,6 +117,16 @@ int mg_cycle_async(mg_handle h, int count);
 int mg_solve(mg_handle h, double tol, int maxit, double *hist, int hist_cap, int *n_hist,
              mg_cycle_stats *per_cycle);
 
+/* Debug stage dumps of the sawtooth cycle -- the reference's CREATE_GIF twin
+ * (multigrid.hpp:160-316) writes `sol + err` sampled on the level being worked on after every
+ * stage: before and after the coarse solve, after each interpolation, after each level's
+ * sweeps, and the corrected solution. With a callback installed mg_cycle does the same
+ * (synchronising after every stage): `values` is a dense host array of n*n*nz elements of the
+ * descriptor's dtype, `stage` counts the calls since the callback was installed (the
+ * reference's frame counter). fn == NULL removes it. Single-GPU handles only. */
+typedef void (*mg_stage_fn)(void *user, int stage, int level, int n, int nz, const void *values);
+int mg_set_stage_callback(mg_handle h, mg_stage_fn fn, void *user);
+
 int mg_sync(mg_handle h);
 /* HIP-event timing on the handle's own stream (torch.cuda.Event would not see it) */
 int mg_timer_start(mg_handle h);

@@ -20,6 +20,7 @@
 #include <array>
 #include <cmath>
 #include <cstddef>
+#include <fstream>
 #include <functional>
 #include <iostream>
 #include <memory>
@@ -162,10 +163,13 @@ namespace detail {
 // One HBM-resident hierarchy deep enough to hold `levels` grids of the given problem.
 class Hierarchy {
 public:
-    Hierarchy(size_t fine_n, double length, double alpha, int levels, int smoother)
+    Hierarchy(size_t fine_n, double length, double alpha, int levels, int smoother, int nu_post = 5,
+              double coarse_tol = 1e-1)
     {
         mg_desc d;
         mg_desc_reference_defaults(&d, static_cast<int>(fine_n), levels, length, alpha, smoother);
+        d.nu_post = nu_post;
+        d.coarse_tol = coarse_tol;
         mg_check(mg_create(&d, -1, &h_));
         n0_ = fine_n;
         levels_ = levels;
@@ -413,9 +417,28 @@ public:
         : A_level(matrices), b(knownVec)
     {
         Domain &d = A_level.front().domain();
+#ifdef CREATE_GIF
+        // the reference's instrumented twin (multigrid.hpp:160-316): nu = 2, coarse tolerance 0.6,
+        // and ./output/<frame>.mtx after every stage (read by test/gifMaker.py)
+        H = std::make_unique<detail::Hierarchy>(d.fineSize(), d.length(), A_level.front().alpha(),
+                                                static_cast<int>(A_level.size()), detail::smoother_id<Smoother>::value,
+                                                2, 0.6);
+        mg_check(mg_set_stage_callback(H->get(), &SawtoothMGIteration::save_frame, nullptr));
+#else
         H = std::make_unique<detail::Hierarchy>(d.fineSize(), d.length(), A_level.front().alpha(),
                                                 static_cast<int>(A_level.size()), detail::smoother_id<Smoother>::value);
+#endif
     }
+#ifdef CREATE_GIF
+    static void save_frame(void *, int stage, int, int n, int nz, const void *values)
+    {
+        std::ofstream file("./output/" + std::to_string(stage) + ".mtx", std::ofstream::trunc);
+        const double *v = static_cast<const double *>(values);
+        const size_t cnt = static_cast<size_t>(n) * n * nz;
+        file << cnt << std::endl;                       // saveVectorOnFile, utilities.hpp:43-54
+        for (size_t i = 0; i < cnt; i++) file << v[i] << std::endl;
+    }
+#endif
     void apply_iteration_to_vec(std::vector<double> &sol)
     {
         H->upload(MG_ARR_RHS, 0, b);

@@ -68,12 +68,13 @@ def build_cli(force: bool = False) -> str:
     return CLI_PATH
 
 
-def build_mirror_harness(out_path: str) -> str:
+def build_mirror_harness(out_path: str, defines=()) -> str:
     """Compiles oracle/ref_harness.cpp -- written against the REFERENCE classes -- unchanged
     against include/multigrid_hip.hpp (tests/cpp/shim/allIncludes.hpp): the drop-in check."""
     build()
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
-    subprocess.run(["g++", "-std=c++20", "-O2", "-w", "-I" + os.path.join(ROOT, "tests", "cpp", "shim"),
+    subprocess.run(["g++", "-std=c++20", "-O2", "-w", *[f"-D{d}" for d in defines],
+                    "-I" + os.path.join(ROOT, "tests", "cpp", "shim"),
                     "-I" + os.path.join(ROOT, "include"), "-I" + HOST,
                     os.path.join(ROOT, "oracle", "ref_harness.cpp"), os.path.join(HOST, "utilities.cpp"),
                     "-L" + LIB_DIR, "-lmg_hip", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib",

@@ -72,6 +72,7 @@ class MgP2POp(C.Structure):
     _fields_ = [("peer", C.c_int32), ("is_send", C.c_int32), ("buf", C.c_void_p), ("bytes", C.c_size_t)]
 
 
+STAGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
 BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(MgP2POp), C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 
@@ -86,7 +87,7 @@ EXPORTS = [
     "mg_level_coefficients", "mg_set_rhs", "mg_set_solution", "mg_get_solution", "mg_set_array",
     "mg_get_array", "mg_zero_array", "mg_smooth", "mg_residual", "mg_sumsq", "mg_restrict",
     "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_coarse_solve_ex", "mg_cycle", "mg_cycle_async", "mg_solve",
-    "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_device_bytes", "mg_comm_unique_id", "mg_comm_selftest",
+    "mg_set_stage_callback", "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_device_bytes", "mg_comm_unique_id", "mg_comm_selftest",
     "mg_create_distributed", "mg_create_distributed_hostcomm", "mg_plan_slab",
 ]
 
@@ -129,6 +130,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.mg_cycle.argtypes = [vp, C.POINTER(MgCycleStats)]
     L.mg_cycle_async.argtypes = [vp, i]
     L.mg_solve.argtypes = [vp, C.c_double, i, dp, i, C.POINTER(i), C.POINTER(MgCycleStats)]
+    L.mg_set_stage_callback.argtypes = [vp, STAGE_FN, vp]
     L.mg_sync.argtypes = [vp]
     L.mg_timer_start.argtypes = [vp]
     L.mg_timer_stop.argtypes = [vp, dp]
@@ -282,6 +284,19 @@ class Solver:
         stats = (MgCycleStats * max(maxit, 1))()
         _check(self.lib.mg_solve(self.h, tol, maxit, hist, maxit + 1, C.byref(nh), stats))
         return np.array(hist[:nh.value]), list(stats[:nh.value - 1])
+
+    def set_stage_callback(self, fn):
+        """fn(stage, level, array) after every stage of the sawtooth cycle (CREATE_GIF dumps); None removes it"""
+        if fn is None:
+            self._stage_cb = STAGE_FN(0)
+        else:
+            def tramp(user, stage, level, n, nz, ptr):
+                shape = (n, n) if self.d.dim == 2 else (nz, n, n)
+                cnt = int(np.prod(shape))
+                buf = (C.c_double if self.d.dtype == MG_F64 else C.c_float) * cnt
+                fn(stage, level, np.ctypeslib.as_array(buf.from_address(ptr)).reshape(shape).copy())
+            self._stage_cb = STAGE_FN(tramp)
+        _check(self.lib.mg_set_stage_callback(self.h, self._stage_cb, None))
 
     def sync(self): _check(self.lib.mg_sync(self.h))
     def timer_start(self): _check(self.lib.mg_timer_start(self.h))

@@ -155,6 +155,11 @@ int mg_solve(mg_handle h, double tol, int maxit, double *hist, int hist_cap, int
     if (maxit < 0) return bad("mg_solve: negative maxit");
     return guarded([&] { return h->impl->solve(tol, maxit, hist, hist_cap, n_hist, per_cycle); });
 }
+int mg_set_stage_callback(mg_handle h, mg_stage_fn fn, void *user)
+{
+    MG_H(h);
+    return guarded([&] { return h->impl->set_stage_callback(fn, user); });
+}
 int mg_sync(mg_handle h) { MG_H(h); return guarded([&] { return h->impl->sync(); }); }
 int mg_timer_start(mg_handle h) { MG_H(h); return guarded([&] { return h->impl->timer_start(); }); }
 int mg_timer_stop(mg_handle h, double *ms) { MG_H(h); return guarded([&] { return h->impl->timer_stop(ms); }); }

@@ -879,9 +879,11 @@ int Solver::cycle_enqueue_t()
         src = MG_ARR_RHS;
     }
     const int rhsL = (L == 1) ? MG_ARR_RES : MG_ARR_RHS;
+    if (stage_fn_) MG_TRY(dump_stage(L - 1, false));
     // :128-131 coarse solve from err == 0
     if (lv_[L - 1].present) MG_TRY(zero_array(MG_ARR_E, L - 1));
     MG_TRY(coarse_level_t<T>(L - 1, MG_ARR_E, rhsL));
+    if (stage_fn_) MG_TRY(dump_stage(L - 1, true));
     // :134-139 prolong (overwrite) + nu sweeps, coarse to fine
     for (int l = L - 2; l >= 0; l--) {
         if (lv_[l].dist && !lv_[l + 1].dist) {
@@ -891,11 +893,14 @@ int Solver::cycle_enqueue_t()
         } else if (lv_[l].present) {
             MG_TRY(prolong_t<T>(l + 1, 0, MG_ARR_E, MG_ARR_E));
         }
+        if (stage_fn_) MG_TRY(dump_stage(l, true));
         if (lv_[l].present)
             MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_E, l == 0 ? MG_ARR_RES : MG_ARR_RHS));
+        if (stage_fn_) MG_TRY(dump_stage(l, true));
     }
     // :141-144
     MG_TRY(correct_t<T>(0, MG_ARR_U, MG_ARR_E));
+    if (stage_fn_) MG_TRY(dump_stage(0, false));
     return MG_OK;
 }
 
@@ -949,6 +954,40 @@ int Solver::solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist
         if (rel <= tol) break;                               // main.cpp:88-89
     }
     if (n_hist) *n_hist = nh;
+    return MG_OK;
+}
+
+int Solver::set_stage_callback(mg_stage_fn fn, void *user)
+{
+    if (fn && nranks_ > 1) { set_last_error("stage dumps are single-GPU only"); return MG_ERR_BAD_ARG; }
+    stage_fn_ = fn; stage_user_ = user; stage_count_ = 0;
+    return MG_OK;
+}
+
+// `sol` sampled on `level` (+ `err` of that level): what the reference's CREATE_GIF twin saves
+// with formatVector(temp, A_level) after temp[id] += err[id] (multigrid.hpp:217-299)
+int Solver::dump_stage(int level, bool add_err)
+{
+    const Level &L0 = lv_[0], &L = lv_[level];
+    const size_t es = esize();
+    const size_t cnt0 = (size_t)L0.g.nx * L0.g.ny * L0.g.nz, cnt = (size_t)L.g.nx * L.g.ny * L.g.nz;
+    stage_u_.resize(cnt0 * es); stage_e_.resize(cnt * es);
+    MG_TRY(get_array(MG_ARR_U, 0, stage_u_.data()));
+    if (add_err) MG_TRY(get_array(MG_ARR_E, level, stage_e_.data()));
+    const int sx = (L0.g.nx - 1) / (L.g.nx - 1);
+    const int sz = (L.g.nz > 1) ? (L0.g.nz - 1) / (L.g.nz - 1) : 1;
+    auto sample = [&](auto *u, auto *e) {
+        for (int k = 0; k < L.g.nz; k++)
+            for (int j = 0; j < L.g.ny; j++)
+                for (int i = 0; i < L.g.nx; i++) {
+                    size_t c = ((size_t)k * L.g.ny + j) * L.g.nx + i;
+                    size_t f = ((size_t)(k * sz) * L0.g.ny + (size_t)j * sx) * L0.g.nx + (size_t)i * sx;
+                    e[c] = add_err ? u[f] + e[c] : u[f];
+                }
+    };
+    if (d_.dtype == MG_F64) sample(reinterpret_cast<double *>(stage_u_.data()), reinterpret_cast<double *>(stage_e_.data()));
+    else sample(reinterpret_cast<float *>(stage_u_.data()), reinterpret_cast<float *>(stage_e_.data()));
+    stage_fn_(stage_user_, stage_count_++, level, L.g.nx, L.g.nz, stage_e_.data());
     return MG_OK;
 }
 

@@ -67,6 +67,7 @@ public:
     int cycle_async(int count);
     int solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist,
               mg_cycle_stats *per_cycle);
+    int set_stage_callback(mg_stage_fn fn, void *user);
     int sync();
     int timer_start();
     int timer_stop(double *ms);
@@ -140,6 +141,12 @@ private:
     Geom stage_g_{};
     void *stage_base_[2] = {nullptr, nullptr};
     std::vector<SlabPlan> planS_;
+    // CREATE_GIF-style stage dumps (mg_set_stage_callback)
+    int dump_stage(int level, bool add_err);
+    mg_stage_fn stage_fn_ = nullptr;
+    void *stage_user_ = nullptr;
+    int stage_count_ = 0;
+    std::vector<char> stage_u_, stage_e_;
     // in-region timing of the finest-grid smoother (mg_profile_begin/end)
     bool profiling_ = false;
     std::vector<hipEvent_t> prof_ev_;

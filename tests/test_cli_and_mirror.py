@@ -196,3 +196,72 @@ def test_mirror_main_loop_reproduces_the_reference_history(mirror_ops):
         m = min(nh, len(ref))
         np.testing.assert_allclose(o[1:1 + m], ref[:m], rtol=2e-3)
         np.testing.assert_allclose(o[1:5], ref[:4], rtol=1e-9)
+
+
+def _expected_frames(po, d, u, b):
+    """The frames the reference's CREATE_GIF twin saves for one cycle (multigrid.hpp:212-299),
+    rebuilt from oracle operators: sol (+ err) sampled on the level being worked on."""
+    ops = po.Ops(d)
+    L = d.levels
+    r, _ = ops.residual(0, u, b)
+    rhs = [r]
+    for l in range(1, L):
+        rhs.append(ops.inject(rhs[-1]))
+    samp = lambda l: np.ascontiguousarray(u[::2 ** l, ::2 ** l])
+    frames = [samp(L - 1)]
+    e = ops.coarse_solve(L - 1, d.smoother, np.zeros_like(rhs[L - 1]), rhs[L - 1], maxit=d.coarse_maxit, tol=d.coarse_tol)[0]
+    frames.append(samp(L - 1) + e)
+    for l in range(L - 2, -1, -1):
+        e = ops.prolong_overwrite(e)
+        frames.append(samp(l) + e)
+        e = ops.smooth(l, d.smoother, d.nu_post, e, rhs[l])
+        frames.append(samp(l) + e)
+    frames.append(u + e)
+    return frames
+
+
+@pytest.mark.gpu
+def test_stage_callback_reproduces_create_gif_frames():
+    """mg_set_stage_callback == the reference's -DCREATE_GIF stage dumps, bit for bit."""
+    from multigrid_prj_amd import capi
+    from oracle import pyoracle as po
+    kw = dict(dim=2, n=33, levels=3, alpha=1.0, length=10.0, smoother=capi.SMOOTH_JACOBI, nu_post=2, coarse_tol=0.6)
+    rng = np.random.default_rng(11)
+    u, b = rng.standard_normal((33, 33)), rng.standard_normal((33, 33))
+    got = []
+    with capi.Solver(capi.make_desc(**kw)) as s:
+        s.set_rhs(b); s.set_solution(u)
+        s.set_stage_callback(lambda stage, level, a: got.append((stage, level, a)))
+        s.cycle()
+        s.set_stage_callback(None)
+        s.cycle()  # no more frames
+    exp = _expected_frames(po, po.make_desc(**kw), u, b)
+    assert [g[0] for g in got] == list(range(len(exp))) == list(range(2 + 2 * 2 + 1))
+    assert [g[1] for g in got] == [2, 2, 1, 1, 0, 0, 0]
+    for (stage, level, a), e in zip(got, exp):
+        assert np.array_equal(a, e), stage
+
+
+@pytest.mark.gpu
+def test_mirror_with_create_gif_writes_the_reference_frame_files(tmp_path):
+    """Built with -DCREATE_GIF the mirror's SawtoothMGIteration switches to nu = 2 / tolerance 0.6
+    and writes ./output/<k>.mtx after every stage, like the reference twin gifMaker.py reads."""
+    exe = mgbuild.build_mirror_harness(os.path.join(ROOT, "tests", "cpp", "_build", "mirror_ops_gif"), defines=("CREATE_GIF",))
+    z = np.load(os.path.join(G, "ref_ops.npz"))
+    m = json.loads(bytes(z["meta_json"]).decode())[0]
+    n, L = m["n"], m["levels"]
+    u, b = z[f"{m['key']}_u"], z[f"{m['key']}_b"]
+    os.makedirs(tmp_path / "output")
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    np.concatenate([u.ravel(), b.ravel()]).astype("<f8").tofile(fin)
+    subprocess.run([exe, "cycle", str(n), str(L), "0", repr(m["alpha"]), repr(m["length"]), "1", "0", str(fin), str(fout)],
+                   check=True, cwd=tmp_path, timeout=300)
+    frames = sorted(os.listdir(tmp_path / "output"), key=lambda f: int(f.split(".")[0]))
+    assert frames == [f"{k}.mtx" for k in range(2 + 2 * (L - 1) + 1)]
+    last = np.loadtxt(tmp_path / "output" / frames[-1])
+    assert int(last[0]) == n * n
+    np.testing.assert_allclose(last[1:], np.fromfile(fout, "<f8"), rtol=2e-5, atol=1e-9)
+    first = np.loadtxt(tmp_path / "output" / "0.mtx")
+    nc = (n - 1) // 2 ** (L - 1) + 1
+    assert int(first[0]) == nc * nc
+    np.testing.assert_allclose(first[1:], u[::2 ** (L - 1), ::2 ** (L - 1)].ravel(), rtol=2e-5, atol=1e-9)
