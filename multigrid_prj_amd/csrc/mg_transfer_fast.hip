@@ -47,7 +47,8 @@ __device__ __forceinline__ void interp_zy(T c00, T c01, T c10, T c11, T Y[4])
     Y[3] = h * (z1y0 + z1y1);        // z odd,  y odd
 }
 
-template <typename T, bool ADD>
+// SEMI: the transition keeps z (semi-coarsening): fine plane z <-> coarse plane z, no z phase
+template <typename T, bool ADD, bool SEMI>
 __global__ __launch_bounds__(64 * PBW) void k_prolong3d_fast(Geom gc, Geom gf, const T *__restrict__ coarse,
                                                              T *__restrict__ fine, int nbx, int nby)
 {
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(64 * PBW) void k_prolong3d_fast(Geom gc, Geom gf, c
     auto col = [&](int m) { return min(ic0 + m, gc.nx - 1); };
     const int yc1 = min(yc + 1, gc.ny - 1);
     // zc+1 may be the coarse upper ghost plane (slab decomposition) -- it is allocated
-    const long long c_z0 = (long long)zc * gc.plane, c_z1 = (long long)(zc + 1) * gc.plane;
+    const long long c_z0 = (long long)zc * gc.plane, c_z1 = SEMI ? c_z0 : (long long)(zc + 1) * gc.plane;
     const long long r0 = (long long)yc * gc.pitch, r1 = (long long)yc1 * gc.pitch;
 
     T Y[CV][4];
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(64 * PBW) void k_prolong3d_fast(Geom gc, Geom gf, c
     }
 
 #pragma unroll
-    for (int zr = 0; zr < 2; zr++) {
-        const int zf = 2 * zc + zr;
+    for (int zr = 0; zr < (SEMI ? 1 : 2); zr++) {
+        const int zf = SEMI ? zc : 2 * zc + zr;
         if (zf >= gf.nz) break;
 #pragma unroll
         for (int yr = 0; yr < 2; yr++) {
@@ -164,7 +165,8 @@ constexpr int ZCC = 4;   // coarse planes per workgroup
 // One workgroup = CR consecutive coarse rows over their whole width: NW waves side by side in
 // x; each lane evaluates the 2*CR+1 fine residual rows those coarse rows need (neighbouring
 // workgroups recompute the shared odd row: 1.5x residual work for CR = 1, 1.25x for CR = 2).
-template <typename T, bool NTLOAD, int CR>
+// SEMI: semi-coarsening transition: every fine plane is a coarse plane, 9-point weights per plane
+template <typename T, bool NTLOAD, int CR, bool SEMI>
 __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coef<T> c, const T *__restrict__ u,
                                                             const T *__restrict__ rhs, T *__restrict__ coarse,
                                                             int nby, int nbz)
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
     const long long ro_hi = (long long)min(2 * J0 + 2 * CR, gf.ny - 1) * gf.pitch + x0c;
     const T q = (T)0.25, h = (T)0.5;
 
-    const int zs = max(2 * K0 - 1, 0), ze = min(2 * (K1 - 1) + 1, gf.nz - 1);  // all inside the grid
+    // fine planes to evaluate (all inside the grid): 2K0-1 .. 2(K1-1)+1, or K0 .. K1-1 when z is kept
+    const int zs = SEMI ? K0 : max(2 * K0 - 1, 0), ze = SEMI ? K1 - 1 : min(2 * (K1 - 1) + 1, gf.nz - 1);
     vec um[NR], uc[NR], up[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) {
@@ -269,15 +272,17 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
         }
         slot ^= 1;
         int emitK = -1;
-        if (z & 1) emitK = (z - 1) >> 1;                 // z = 2K+1 closes coarse plane K
+        if (SEMI) emitK = z;                             // planes map one to one
+        else if (z & 1) emitK = (z - 1) >> 1;            // z = 2K+1 closes coarse plane K
         else if (z == gf.nz - 1) emitK = z >> 1;         // top boundary plane has no z+1: it injects
+        const bool centre = SEMI || !(z & 1);
 #pragma unroll
         for (int j = 0; j < CR; j++) {
             const int J = J0 + j;
             T yw[CV];
 #pragma unroll
             for (int m = 0; m < CV; m++) yw[m] = q * xw[2 * j][m] + h * xw[2 * j + 1][m] + q * xw[2 * j + 2][m];
-            if (!(z & 1)) {                              // z = 2K: centre plane
+            if (centre) {                                // z = 2K (or any plane when z is kept): centre plane
 #pragma unroll
                 for (int m = 0; m < CV; m++) { ywc[j][m] = yw[m]; ctr[j][m] = res[2 * j + 1][2 * m]; }
                 if (tail_lane) {  // odd last fine column (Dirichlet): r = rhs - u on the centre row
@@ -293,12 +298,12 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
                 for (int m = 0; m < CV; m++) {
                     const int I = ic0 + m;
                     const bool Ibnd = (I == 0) || (I == gc.nx - 1);
-                    const T fw = q * ywm[j][m] + h * ywc[j][m] + q * yw[m];
+                    const T fw = SEMI ? yw[m] : q * ywm[j][m] + h * ywc[j][m] + q * yw[m];
                     if (cin) coarse[co + I] = (Kbnd || Jbnd || Ibnd) ? ctr[j][m] : fw;
                 }
                 if (tail_lane) coarse[co + gc.nx - 1] = ctr_tail[j];  // coarse column nc-1 is a boundary node
             }
-            if (z & 1) {
+            if (!SEMI && (z & 1)) {
 #pragma unroll
                 for (int m = 0; m < CV; m++) ywm[j][m] = yw[m];
             }
@@ -310,12 +315,15 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
 
 }  // namespace
 
+static bool transfer_is_semi(const Geom &gf, const Geom &gc) { return gf.dim == 3 && gf.gnz == gc.gnz && gf.gnz > 1; }
+
 template <typename T>
 bool prolong_fast_ok(const Geom &gc, const Geom &gf)
 {
     constexpr int V = PV<T>::V;
-    return gf.dim == 3 && gf.nx == 2 * gc.nx - 1 && gf.ny == 2 * gc.ny - 1 && gc.nx >= 17 && (gf.nx % V) == 1 &&
-           gf.gz0 == 2 * gc.gz0 && gf.nz <= 2 * gc.nz && gf.nz >= 2 * gc.nz - 1;
+    if (!(gf.dim == 3 && gf.nx == 2 * gc.nx - 1 && gf.ny == 2 * gc.ny - 1 && gc.nx >= 17 && (gf.nx % V) == 1)) return false;
+    if (transfer_is_semi(gf, gc)) return gf.gz0 == gc.gz0 && gf.nz == gc.nz;
+    return gf.gz0 == 2 * gc.gz0 && gf.nz <= 2 * gc.nz && gf.nz >= 2 * gc.nz - 1;
 }
 
 template <typename T>
@@ -327,8 +335,13 @@ void launch_prolong_fast(hipStream_t s, const Geom &gc, const Geom &gf, const T 
     const int nbx = (ncol + 64 * CV - 1) / (64 * CV);
     const int nby = (gc.ny + PBW - 1) / PBW;
     dim3 gr(nbx * nby, gc.nz), bl(64 * PBW);
-    if (add) hipLaunchKernelGGL((k_prolong3d_fast<T, true>), gr, bl, 0, s, gc, gf, coarse, fine, nbx, nby);
-    else hipLaunchKernelGGL((k_prolong3d_fast<T, false>), gr, bl, 0, s, gc, gf, coarse, fine, nbx, nby);
+    if (transfer_is_semi(gf, gc)) {
+        if (add) hipLaunchKernelGGL((k_prolong3d_fast<T, true, true>), gr, bl, 0, s, gc, gf, coarse, fine, nbx, nby);
+        else hipLaunchKernelGGL((k_prolong3d_fast<T, false, true>), gr, bl, 0, s, gc, gf, coarse, fine, nbx, nby);
+    } else {
+        if (add) hipLaunchKernelGGL((k_prolong3d_fast<T, true, false>), gr, bl, 0, s, gc, gf, coarse, fine, nbx, nby);
+        else hipLaunchKernelGGL((k_prolong3d_fast<T, false, false>), gr, bl, 0, s, gc, gf, coarse, fine, nbx, nby);
+    }
 }
 
 template bool prolong_fast_ok<double>(const Geom &, const Geom &);
@@ -344,7 +357,8 @@ template <typename T>
 bool resid_restrict_fast_ok(const Geom &gf, const Geom &gc)
 {
     constexpr int V = PV<T>::V;
-    return gf.dim == 3 && gf.nx == 2 * gc.nx - 1 && gf.ny == 2 * gc.ny - 1 && gf.nz == 2 * gc.nz - 1 &&
+    const bool zok = transfer_is_semi(gf, gc) ? gf.nz == gc.nz : gf.nz == 2 * gc.nz - 1;
+    return gf.dim == 3 && gf.nx == 2 * gc.nx - 1 && gf.ny == 2 * gc.ny - 1 && zok &&
            gf.gz0 == 0 && gc.gz0 == 0 && gf.gnz == gf.nz && gc.gnz == gc.nz && gc.nx >= 17 && (gf.nx % V) == 1 &&
            (gc.nx - 1 + 64 * (V / 2) - 1) / (64 * (V / 2)) <= 8;
 }
@@ -361,8 +375,13 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
     const int nbz = (gc.nz + ZCC - 1) / ZCC;
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool nt = (size_t)gf.nz * gf.plane * sizeof(T) >= ((size_t)64 << 20);
-    if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
-    else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
+    if (transfer_is_semi(gf, gc)) {
+        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
+        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
+    } else {
+        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
+        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
+    }
 }
 
 template bool resid_restrict_fast_ok<double>(const Geom &, const Geom &);
