@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64 * PBW) void k_prolong3d_fast(Geom gc, Geom gf, c
 {
     constexpr int V = PV<T>::V, CV = V / 2;
     typedef typename PV<T>::vec vec;
+    (void)nby;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
     const int zc = blockIdx.y;                     // local coarse plane; fine planes 2zc, 2zc+1

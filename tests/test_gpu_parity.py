@@ -285,3 +285,42 @@ def test_manufactured_solution_second_order():
 def test_invalid_descriptor_is_refused():
     with pytest.raises(capi.MgError):
         capi.Solver(capi.make_desc(n=200, levels=2))  # the reference's own defaults (utilities.hpp:16,19)
+
+
+EDGE = [
+    dict(dim=2, n=3, levels=1), dict(dim=2, n=5, levels=2), dict(dim=2, n=17, levels=1), dict(dim=2, n=19, levels=2),
+    dict(dim=3, n=3, levels=1), dict(dim=3, n=5, levels=2), dict(dim=3, n=9, levels=3), dict(dim=3, n=11, levels=2),
+]
+
+
+@pytest.mark.parametrize("case", EDGE, ids=lambda c: f"{c['dim']}d-n{c['n']}-L{c['levels']}")
+@pytest.mark.parametrize("smoother", [capi.SMOOTH_GS_LEX, capi.SMOOTH_JACOBI])
+def test_edge_grids_smallest_and_single_level(case, smoother):
+    """Smallest admissible grids (3 nodes per side on the coarsest level, one interior node),
+    single-level hierarchies (the cycle degenerates to the coarse solver on the finest grid,
+    SURVEY appendix A) and odd multiples m*2^(L-1)+1."""
+    kw = dict(alpha=1.3, length=2.0, smoother=smoother, **case)
+    sg = capi.Solver(capi.make_desc(**kw)); so = po.Solver(po.make_desc(**kw))
+    rng = np.random.default_rng(21)
+    with sg:
+        b = rng.standard_normal(sg.level_shape(0))
+        sg.set_rhs(b); so.set_rhs(b)
+        for _ in range(2):
+            stg, sto = sg.cycle(), so.cycle()
+            assert (stg.coarse_iters, stg.coarse_flag) == (sto.coarse_iters, sto.coarse_flag)
+        assert np.array_equal(sg.get_solution(), so.get_solution())
+
+
+def test_zero_right_hand_side_gives_nan_norms_like_the_reference():
+    """Norm() = sqrt(0/0) = NaN; `NaN > tol` and `NaN <= TOL` are both false, so the reference's
+    coarse loop exits at once and its outer loop runs to MaxIter. Same here."""
+    kw = dict(dim=2, n=17, levels=2, smoother=capi.SMOOTH_JACOBI)
+    with capi.Solver(capi.make_desc(**kw)) as s:
+        s.set_rhs(np.zeros((17, 17)))
+        hist, stats = s.solve(1e-11, 3)
+        assert len(hist) == 4 and np.isnan(hist).all()
+        assert all(st.coarse_iters == 0 and st.coarse_flag == 0 for st in stats)
+        assert not s.get_solution().any()
+    o = po.Solver(po.make_desc(**kw)); o.set_rhs(np.zeros((17, 17)))
+    ho, so = o.solve(1e-11, 3)
+    assert len(ho) == 4 and np.isnan(ho).all() and all(st.coarse_iters == 0 for st in so)
