@@ -21,6 +21,8 @@
 // MFMA is not used: there is no contraction here, the kernel is HBM-bound (24 B/point).
 #include "mg_kernels.h"
 
+#include <cstdlib>
+
 namespace mg {
 namespace {
 
@@ -212,6 +214,180 @@ __global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Fused double Jacobi sweep: out = J(J(u)) in ONE pass over HBM (temporal blocking, V(2,2)'s
+// sweep pairs). Workgroup = TPR threads = one full grid row (TPR vectors + the odd tail column)
+// x TYO output rows, marching ZC planes. Per plane p: (1) the first sweep v(p) on TYO+2 rows
+// (overlapped tiling in y) from u planes p-1, p, p+1 held in registers; (2) the second sweep on
+// plane q = p-1 of the TYO output rows: its z-neighbours v(q-1), v(q+1) are the thread's own
+// registers, its x/y-neighbours come from the LDS copy of v(q) published one step earlier;
+// (3) v(p) is published to the other LDS slot; one barrier per plane. Same per-point
+// arithmetic as two k_sweep3d launches => bit-identical; measured 1.10 ms vs 1.23 ms per pair
+// at 513^3 fp64 (profiles/r01_kbench_fused_double_sweep.log) -- it trades HBM traffic for
+// redundant halo rows and a low occupancy (2 waves/SIMD), hence only ~10 %.
+constexpr int J2_TYO = 2, J2_ZC = 16;
+
+template <typename T, int TPR, bool DAMPED, bool NTLOAD>
+__global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
+                                                 const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz)
+{
+    constexpr int V = VecOf<T>::V, TYO = J2_TYO, ZC = J2_ZC, TYV = TYO + 2;
+    constexpr int LP = TPR * V + 2 * V;  // LDS row: V pad | TPR*V values | tail column | pad
+    typedef typename VecOf<T>::type vec;
+    __shared__ __align__(16) T lds[2][TYV][LP];
+    const int nblocks = nby * nbz;
+    const int per = (nblocks + 7) >> 3;
+    const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order
+    if (bid >= nblocks) return;                                   // whole workgroup
+    const int by = bid % nby, bz = bid / nby;
+    const int t = threadIdx.x, lane = t & 63;
+    const int x0 = V * t;                       // the gate guarantees nx - 1 == TPR * V
+    const bool tail = (x0 + V == g.nx - 1);     // last thread: also owns the Dirichlet column nx-1
+    const bool tailwave = (t >> 6) == (TPR >> 6) - 1;
+    const int y0 = by * TYO;                    // output rows y0 .. y0+TYO-1; v rows y0-1 .. y0+TYO
+    const int z0 = bz * ZC, z1 = min(z0 + ZC, g.nz);
+    long long ro[TYV];
+    bool ybnd[TYV];
+#pragma unroll
+    for (int r = 0; r < TYV; r++) {
+        const int y = min(max(y0 - 1 + r, 0), g.ny - 1);
+        ybnd[r] = (y == 0) || (y == g.ny - 1);
+        ro[r] = (long long)y * g.pitch + x0;
+    }
+    const long long ro_lo = (long long)min(max(y0 - 2, 0), g.ny - 1) * g.pitch + x0;
+    const long long ro_hi = (long long)min(y0 + TYO + 1, g.ny - 1) * g.pitch + x0;
+    auto plane_of = [&](int p) { return (long long)min(max(p, -1), g.nz) * g.plane; };  // stay inside the allocation
+
+    vec um[TYV], uc[TYV], up[TYV];
+    vec vm[TYO], vc[TYO], vp[TYO];  // own-column v(q-1), v(q), v(q+1) of the output rows
+    vec bq[TYO];                    // rhs of the output rows on plane q
+#pragma unroll
+    for (int r = 0; r < TYV; r++) {
+        um[r] = *(const vec *)(u + plane_of(z0 - 2) + ro[r]);
+        uc[r] = *(const vec *)(u + plane_of(z0 - 1) + ro[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < TYO; r++) { vm[r] = (vec)(0); vc[r] = (vec)(0); bq[r] = (vec)(0); }
+
+    for (int p = z0 - 1; p <= z1; p++) {
+        const long long po = plane_of(p);
+        const T *pu = u + po;
+        // planes outside the grid (p = -1 or nz, first / last chunk only) are never evaluated: their
+        // v only feeds Dirichlet outputs, and the wave-edge load of row 0 on plane -1 would fall
+        // in front of the allocation
+        const bool pin = (p >= 0) && (p < g.nz);
+        vec b[TYV], v[TYV];
+        T vtail[TYV];
+#pragma unroll
+        for (int r = 0; r < TYV; r++) {
+            up[r] = *(const vec *)(u + plane_of(p + 1) + ro[r]);
+            b[r] = (vec)(0); v[r] = (vec)(0); vtail[r] = 0;
+        }
+        if (pin) {
+#pragma unroll
+            for (int r = 0; r < TYV; r++) {
+                if (NTLOAD && r >= 1 && r <= TYO) b[r] = *(const vec *)(rhs + po + ro[r]);
+                else b[r] = *(const vec *)(rhs + po + ro[r]);
+            }
+            const vec hlo = *(const vec *)(pu + ro_lo);
+            const vec hhi = *(const vec *)(pu + ro_hi);
+            const bool zbp = (p == 0) || (p == g.nz - 1);
+#pragma unroll
+            for (int r = 0; r < TYV; r++) {
+                T el = 0, er = 0;
+                if (lane == 0) el = pu[ro[r] - 1];
+                if (lane == 63) er = pu[ro[r] + V];
+                const T xm = from_prev_lane(uc[r][V - 1], el);
+                const T xp = from_next_lane(uc[r][0], er);
+                const vec ym = (r > 0) ? uc[r > 0 ? r - 1 : 0] : hlo;
+                const vec yp = (r < TYV - 1) ? uc[r < TYV - 1 ? r + 1 : 0] : hhi;
+                const bool rb = zbp || ybnd[r];
+#pragma unroll
+                for (int e = 0; e < V; e++) {
+                    const T left = (e == 0) ? xm : uc[r][e > 0 ? e - 1 : 0];
+                    const T right = (e == V - 1) ? xp : uc[r][e < V - 1 ? e + 1 : 0];
+                    T sum = 0;
+                    sum += c.cz * um[r][e];
+                    sum += c.cy * ym[e];
+                    sum += c.cx * left;
+                    sum += c.cx * right;
+                    sum += c.cy * yp[e];
+                    sum += c.cz * up[r][e];
+                    T jac = (b[r][e] - sum) / c.cd;
+                    if (DAMPED) jac = uc[r][e] + omega * (jac - uc[r][e]);
+                    v[r][e] = (rb || (x0 + e == 0)) ? b[r][e] : jac;
+                }
+                if (tail) vtail[r] = rhs[po + ro[r] + V];  // first sweep on the Dirichlet column: v = rhs
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < TYO; r++) vp[r] = v[r + 1];
+        // ---- second sweep on plane q = p-1
+        const int q = p - 1;
+        if (q >= z0 && q < z1) {
+            const bool zbq = (q == 0) || (q == g.nz - 1);
+            const int sl = q & 1;
+            const long long qo = (long long)q * g.plane;
+#pragma unroll
+            for (int r = 0; r < TYO; r++) {
+                const int y = y0 + r;
+                if (y < g.ny) {
+                    const int lr = r + 1;
+                    const T xm = lds[sl][lr][V + x0 - 1], xp = lds[sl][lr][V + x0 + V];
+                    const vec ym = *(const vec *)&lds[sl][lr - 1][V + x0];
+                    const vec yp = *(const vec *)&lds[sl][lr + 1][V + x0];
+                    const bool rb = zbq || (y == 0) || (y == g.ny - 1);
+                    vec res;
+#pragma unroll
+                    for (int e = 0; e < V; e++) {
+                        const T left = (e == 0) ? xm : vc[r][e > 0 ? e - 1 : 0];
+                        const T right = (e == V - 1) ? xp : vc[r][e < V - 1 ? e + 1 : 0];
+                        T sum = 0;
+                        sum += c.cz * vm[r][e];
+                        sum += c.cy * ym[e];
+                        sum += c.cx * left;
+                        sum += c.cx * right;
+                        sum += c.cy * yp[e];
+                        sum += c.cz * vp[r][e];
+                        T jac = (bq[r][e] - sum) / c.cd;
+                        if (DAMPED) jac = vc[r][e] + omega * (jac - vc[r][e]);
+                        res[e] = (rb || (x0 + e == 0)) ? bq[r][e] : jac;
+                    }
+                    __builtin_nontemporal_store(res, (vec *)(out + qo + ro[lr]));
+                    if (tailwave && lane >= 56) {
+                        // column nx-1 (Dirichlet) as one full 128-byte line: value + zero padding
+                        const int j = lane - 56;
+                        constexpr int LINE = 128 / (int)sizeof(T);
+                        const int xs = g.nx - 1 + V * j;
+                        const int line_end = ((g.nx - 1) / LINE + 1) * LINE;
+                        if (xs < line_end) {
+                            const long long rb0 = qo + (ro[lr] - x0);
+                            vec tv = (vec)(0);
+                            if (j == 0) tv[0] = rhs[rb0 + g.nx - 1];
+                            __builtin_nontemporal_store(tv, (vec *)(out + rb0 + xs));
+                        }
+                    }
+                }
+            }
+        }
+        // ---- publish v(p) for the next plane's x/y neighbours
+        {
+            const int sl = p & 1;
+#pragma unroll
+            for (int r = 0; r < TYV; r++) {
+                *(vec *)&lds[sl][r][V + x0] = v[r];
+                if (tail) lds[sl][r][V + x0 + V] = vtail[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < TYV; r++) { um[r] = uc[r]; uc[r] = up[r]; }
+#pragma unroll
+        for (int r = 0; r < TYO; r++) { vm[r] = vc[r]; vc[r] = vp[r]; bq[r] = b[r + 1]; }
+    }
+}
+
 struct FastGrid { int nbx, nby, nbz, grid; };
 template <typename T>
 FastGrid fast_grid(const Geom &g)
@@ -289,6 +465,41 @@ int launch_residual_fast(hipStream_t s, const Geom &g, const Coef<T> &c, const T
     return want_norm ? f.grid : 0;
 }
 
+// fused double sweep: whole (non-distributed) 3-D level whose rows are exactly 64/128/256 vectors
+// + the odd column; opt out with MG_FUSED_PAIR=0
+template <typename T>
+bool jacobi2_ok(const Geom &g)
+{
+    constexpr int V = VecOf<T>::V;
+    static const bool enabled = [] { const char *e = getenv("MG_FUSED_PAIR"); return !(e && e[0] == '0'); }();
+    if (!enabled || g.dim != 3 || g.gz0 != 0 || g.gnz != g.nz || g.ny < 3 || g.nz < 3) return false;
+    const int v = (g.nx - 1) / V;
+    return (g.nx - 1) % V == 0 && (v == 64 || v == 128 || v == 256);
+}
+
+template <typename T>
+void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out)
+{
+    constexpr int V = VecOf<T>::V;
+    const int tpr = (g.nx - 1) / V;
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = (g.nz + J2_ZC - 1) / J2_ZC;
+    const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
+    const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
+#define MG_J2(TPR) \
+    do { \
+        if (damped) { if (nt) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz); \
+                      else hipLaunchKernelGGL((k_jacobi2<T, TPR, true, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz); } \
+        else { if (nt) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz); \
+               else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz); } \
+    } while (0)
+    if (tpr == 256) MG_J2(256); else if (tpr == 128) MG_J2(128); else MG_J2(64);
+#undef MG_J2
+}
+
+template bool jacobi2_ok<double>(const Geom &);
+template bool jacobi2_ok<float>(const Geom &);
+template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *);
+template void launch_jacobi2<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *);
 template bool fast_path_ok<double>(const Geom &);
 template bool fast_path_ok<float>(const Geom &);
 template int fast_partials_capacity<double>(const Geom &);

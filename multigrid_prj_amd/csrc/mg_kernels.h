@@ -24,6 +24,10 @@ template <typename T> int fast_partials_capacity(const Geom &g);
 template <typename T>
 void launch_jacobi_fast(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u,
                         const T *rhs, T *out, bool zero_u);
+// two Jacobi sweeps in one pass (out = J(J(u))), see mg_jacobi_fast.hip
+template <typename T> bool jacobi2_ok(const Geom &g);
+template <typename T>
+void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out);
 // out-of-place colour half-sweep (the other colour is copied): red u->tmp, black tmp->u
 template <typename T>
 void launch_rb_fast(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, const T *u, const T *rhs, T *out);

@@ -527,6 +527,13 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
     switch (smoother) {
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
+            if (!L.dist && !(x_zero && s == 0) && s + 1 < sweeps && jacobi2_ok<T>(L.g)) {
+                // two sweeps in one pass over HBM; the pair lands in TMP like a single sweep would
+                launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level));
+                std::swap(L.base[ax], L.base[MG_ARR_TMP]);
+                s++;
+                continue;
+            }
             const bool zero_now = x_zero && s == 0;
             T *px = ptr<T>(ax, level), *pr = ptr<T>(ar, level), *pt = ptr<T>(MG_ARR_TMP, level);
             if (zero_now) {

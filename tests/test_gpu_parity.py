@@ -267,6 +267,24 @@ def test_full_size_jacobi_and_residual_513():
         assert ss == pytest.approx(ss_ref, rel=1e-11)
 
 
+@pytest.mark.parametrize("n,dtype,omega", [(129, capi.MG_F64, 6 / 7), (257, capi.MG_F64, 1.0), (257, capi.MG_F32, 6 / 7),
+                                           (513, capi.MG_F64, 6 / 7)])
+def test_fused_double_sweep_equals_two_sweeps(n, dtype, omega):
+    """k_jacobi2 (two Jacobi sweeps in one pass, row widths 64 / 128 / 256 vectors) against two
+    oracle sweeps, bit for bit, on whole grids including the 513^3 headline size."""
+    kw = dict(dim=3, n=n, levels=2, dtype=dtype, length=1.0, alpha=1.0, omega=omega)
+    s, ops, do = pair(**kw)
+    rng = np.random.default_rng(9)
+    with s:
+        u = rng.random((n, n, n)).astype(s.np); b = rng.random((n, n, n)).astype(s.np)
+        s.set_array(capi.ARR_U, 0, u); s.set_array(capi.ARR_RHS, 0, b)
+        s.smooth(0, capi.SMOOTH_JACOBI, 2, capi.ARR_U, capi.ARR_RHS)      # one fused pair
+        ref2 = ops.smooth(0, po.SMOOTH_JACOBI, 2, u, b)
+        assert np.array_equal(s.get_array(capi.ARR_U, 0), ref2)
+        s.smooth(0, capi.SMOOTH_JACOBI, 3, capi.ARR_U, capi.ARR_RHS)      # a pair + a single sweep
+        assert np.array_equal(s.get_array(capi.ARR_U, 0), ops.smooth(0, po.SMOOTH_JACOBI, 3, ref2, b))
+
+
 def test_manufactured_solution_second_order():
     """3-D accuracy check with no oracle in the loop: u* = sin sin sin, error O(h^2)."""
     errs = []
