@@ -155,6 +155,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     sm_ms, sm_sweeps = s.profile_end()
+    fu_ms, fu_sweeps = s.profile_fused()   # post-smoothing pairs that also carried the prolongation
     elapsed = t1 - t0
     if dist is not None:
         import torch
@@ -203,6 +204,12 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_src, "sweep_ms": sweep_ms, "sweeps_timed": sm_sweeps,
                      "algorithmic_bytes_per_sweep": bytes_per_sweep},
         "smoother_gbps": achieved,
+        # one launch = prolong-add (read u, read coarse, write u: not executed as such) + two sweeps
+        "prolong_folded_pair": ({"kernel": "k_jacobi2<CORR>: J(J(u + P e)) in one pass", "launch_ms": 2 * fu_ms / fu_sweeps,
+                                 "launches_timed": fu_sweeps // 2,
+                                 "replaces_bytes": 2 * bytes_per_sweep + int(2.125 * esz * pts_local),
+                                 "equivalent_gbps": (2 * bytes_per_sweep + 2.125 * esz * pts_local) / (2 * fu_ms / fu_sweeps * 1e-3) / 1e9}
+                                if fu_sweeps else None),
         "residual_drop_per_cycle": float(hist[-1] / hist[-2]) if len(hist) >= 2 and hist[-2] > 0 else None,
         "device_bytes": s.device_bytes(),
     }

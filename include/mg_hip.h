@@ -137,6 +137,10 @@ int mg_timer_stop(mg_handle h, double *milliseconds);
  * sweeps (kernel launches; a red-black sweep counts once, both colours included). */
 int mg_profile_begin(mg_handle h);
 int mg_profile_end(mg_handle h, double *smoother_ms, int *smoother_sweeps);
+/* A V-cycle folds the prolongation into the first post-smoothing pair when it can (one
+ * launch computing J(J(u + P e))); those segments are not smoother-only work, so they are
+ * left out of mg_profile_end's totals and reported here (valid after mg_profile_end). */
+int mg_profile_fused(mg_handle h, double *fused_ms, int *fused_sweeps);
 /* bytes of HBM held by the handle */
 int mg_device_bytes(mg_handle h, size_t *bytes);
 

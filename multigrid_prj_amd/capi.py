@@ -87,7 +87,7 @@ EXPORTS = [
     "mg_level_coefficients", "mg_set_rhs", "mg_set_solution", "mg_get_solution", "mg_set_array",
     "mg_get_array", "mg_zero_array", "mg_smooth", "mg_residual", "mg_sumsq", "mg_restrict",
     "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_coarse_solve_ex", "mg_cycle", "mg_cycle_async", "mg_solve",
-    "mg_set_stage_callback", "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_device_bytes", "mg_comm_unique_id", "mg_comm_selftest",
+    "mg_set_stage_callback", "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_profile_fused", "mg_device_bytes", "mg_comm_unique_id", "mg_comm_selftest",
     "mg_create_distributed", "mg_create_distributed_hostcomm", "mg_plan_slab",
 ]
 
@@ -136,6 +136,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.mg_timer_stop.argtypes = [vp, dp]
     L.mg_profile_begin.argtypes = [vp]
     L.mg_profile_end.argtypes = [vp, dp, C.POINTER(i)]
+    L.mg_profile_fused.argtypes = [vp, dp, C.POINTER(i)]
     L.mg_device_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.mg_comm_unique_id.argtypes = [vp]
     L.mg_comm_selftest.argtypes = [C.c_size_t]
@@ -310,6 +311,12 @@ class Solver:
         """-> (summed ms of the finest-grid smoother calls, number of sweeps)"""
         ms = C.c_double(0); n = C.c_int(0)
         _check(self.lib.mg_profile_end(self.h, C.byref(ms), C.byref(n))); return ms.value, n.value
+
+    def profile_fused(self):
+        """-> (summed ms, sweeps) of the finest-grid launches that also carried the prolongation
+        (valid after profile_end)"""
+        ms = C.c_double(0); n = C.c_int(0)
+        _check(self.lib.mg_profile_fused(self.h, C.byref(ms), C.byref(n))); return ms.value, n.value
 
     def device_bytes(self) -> int:
         b = C.c_size_t(0); _check(self.lib.mg_device_bytes(self.h, C.byref(b))); return b.value

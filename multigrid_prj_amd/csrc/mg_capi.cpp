@@ -165,6 +165,7 @@ int mg_timer_start(mg_handle h) { MG_H(h); return guarded([&] { return h->impl->
 int mg_timer_stop(mg_handle h, double *ms) { MG_H(h); return guarded([&] { return h->impl->timer_stop(ms); }); }
 int mg_profile_begin(mg_handle h) { MG_H(h); return guarded([&] { return h->impl->profile_begin(); }); }
 int mg_profile_end(mg_handle h, double *ms, int *sweeps) { MG_H(h); return guarded([&] { return h->impl->profile_end(ms, sweeps); }); }
+int mg_profile_fused(mg_handle h, double *ms, int *sweeps) { MG_H(h); return guarded([&] { return h->impl->profile_fused(ms, sweeps); }); }
 int mg_device_bytes(mg_handle h, size_t *bytes)
 {
     MG_H(h);

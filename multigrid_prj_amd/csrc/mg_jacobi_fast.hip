@@ -228,11 +228,19 @@ __global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
 // redundant halo rows and a low occupancy (2 waves/SIMD), hence only ~10 %.
 constexpr int J2_TYO = 2, J2_ZC = 16;
 
-template <typename T, int TPR, bool DAMPED, bool NTLOAD>
+// CORR: every u value read is u + P e_coarse computed on the fly (the V-cycle's prolong-add folded
+// into the post-smoothing pair: the corrected fine array is never written). P e is built with the
+// prolongation's own expression tree -- z midpoints, then y, then x, each 0.5*(a+b) -- from the
+// coarse values of 4 coarse rows per plane (own columns + DPP neighbours, L1/L2-hot), so
+// u + P e has exactly the bits k_prolong3d_fast<ADD> would have stored.
+template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false>
 __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
-                                                 const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz)
+                                                 const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz,
+                                                 const T *__restrict__ coarse, Geom gc)
 {
     constexpr int V = VecOf<T>::V, TYO = J2_TYO, ZC = J2_ZC, TYV = TYO + 2;
+    constexpr int CV = V / 2;  // coarse columns owned by this thread
+    static_assert(!CORR || TYO == 2, "the correction assumes two output rows (y0 even)");
     constexpr int LP = TPR * V + 2 * V;  // LDS row: V pad | TPR*V values | tail column | pad
     typedef typename VecOf<T>::type vec;
     __shared__ __align__(16) T lds[2][TYV][LP];
@@ -259,13 +267,117 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
     const long long ro_hi = (long long)min(y0 + TYO + 1, g.ny - 1) * g.pitch + x0;
     auto plane_of = [&](int p) { return (long long)min(max(p, -1), g.nz) * g.plane; };  // stay inside the allocation
 
+    // ---- on-the-fly prolongation (CORR) ------------------------------------------------------
+    // Per coarse row the thread loads its own CV columns (one coalesced 8-byte load); the column to
+    // the right comes from the next lane by DPP; the wave's edge lanes load the one column a
+    // neighbouring wave owns (lane 0: left, for u(x0-1); lane 63: right), merged into one load.
+    // A correction "row" is NR values: [0..CV) own columns, [CV] right column, [CV+1] edge column.
+    constexpr int NR = CV + 2;
+    const T hf = (T)0.5;
+    typedef T cvec __attribute__((ext_vector_type(CV > 1 ? CV : 2)));
+    int crow[4];   // offsets of coarse rows yc0-1 .. yc0+2 (clamped into the grid) + own first column
+    int ecol = 0;  // edge lanes: column offset relative to the own first column
+    if (CORR) {
+        const int yc0 = y0 >> 1, ic0 = CV * t;
+#pragma unroll
+        for (int j = 0; j < 4; j++) crow[j] = min(max(yc0 - 1 + j, 0), gc.ny - 1) * gc.pitch + ic0;
+        ecol = (lane == 0) ? (ic0 > 0 ? -1 : 0) : (lane == 63 ? CV : 0);
+    }
+    auto load_crow = [&](const T *base, int j, T (&d)[NR]) {
+        if (CV == 1) d[0] = base[crow[j]];
+        else {
+            const cvec w = *(const cvec *)(base + crow[j]);
+#pragma unroll
+            for (int m = 0; m < CV; m++) d[m] = w[m];
+        }
+        d[CV] = 0;
+        d[CV + 1] = base[crow[j] + ecol];  // only the edge lanes' value is consumed (ecol = 0 elsewhere)
+    };
+    // Loads and arithmetic are kept apart so that a plane step issues ALL its loads (u, rhs,
+    // coarse) before the first wait: raw_a/raw_b only load, zfin only computes.
+    auto cplane = [&](int P, int up1) { return coarse + (long long)((min(max(P, 0), g.nz - 1) + up1) >> 1) * gc.plane; };
+    auto raw_a = [&](int P, T (&R)[4][NR]) {
+        const T *c0 = cplane(P, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) load_crow(c0, j, R[j]);
+    };
+    auto raw_b = [&](int P, T (&R)[4][NR]) {  // the upper coarse plane of an odd fine plane
+        if (P & 1) {
+            const T *c1 = cplane(P, 1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) load_crow(c1, j, R[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int m = 0; m < NR; m++) R[j][m] = 0;
+        }
+    };
+    // Z[j][.]: coarse correction interpolated in z onto fine plane P (zero outside the grid)
+    auto zfin = [&](int P, const T (&Ra)[4][NR], const T (&Rb)[4][NR], T (&Z)[4][NR]) {
+        const bool in = (P >= 0) && (P < g.nz), odd = (P & 1) != 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int m = 0; m < NR; m++) {
+                const T z = odd ? hf * (Ra[j][m] + Rb[j][m]) : Ra[j][m];
+                Z[j][m] = in ? z : (T)0;
+            }
+            Z[j][CV] = from_next_lane(Z[j][0], Z[j][CV + 1]);
+        }
+    };
+    auto zrows = [&](int P, T (&Z)[4][NR]) {
+        T Ra[4][NR], Rb[4][NR];
+        raw_a(P, Ra); raw_b(P, Rb); zfin(P, Ra, Rb, Z);
+    };
+    // y-interpolated rows from Z: index 0 = halo row y0-2, 1..4 = v rows y0-1 .. y0+2, 5 = halo row y0+3
+    auto yrows = [&](const T (&Z)[4][NR], T (&Y)[6][NR]) {
+#pragma unroll
+        for (int m = 0; m < NR; m++) {
+            Y[0][m] = Z[0][m];
+            Y[1][m] = hf * (Z[0][m] + Z[1][m]);
+            Y[2][m] = Z[1][m];
+            Y[3][m] = hf * (Z[1][m] + Z[2][m]);
+            Y[4][m] = Z[2][m];
+            Y[5][m] = hf * (Z[2][m] + Z[3][m]);
+        }
+    };
+    // P e on the thread's own vector of a row / on its left and right wave-edge neighbours
+    auto pe_vec = [&](const T (&Yr)[NR]) {
+        vec w;
+#pragma unroll
+        for (int mm = 0; mm < CV; mm++) {
+            w[2 * mm] = Yr[mm];
+            w[2 * mm + 1] = hf * (Yr[mm] + Yr[mm + 1]);
+        }
+        return w;
+    };
+    auto pe_left = [&](const T (&Yr)[NR]) { return hf * (Yr[CV + 1] + Yr[0]); };  // x0-1 (odd); lane 0 only
+    auto pe_right = [&](const T (&Yr)[NR]) { return Yr[CV]; };                     // x0+V (even)
+    auto add_vec = [&](vec a, vec w) {
+        vec o;
+#pragma unroll
+        for (int e = 0; e < V; e++) o[e] = a[e] + w[e];
+        return o;
+    };
+
     vec um[TYV], uc[TYV], up[TYV];
     vec vm[TYO], vc[TYO], vp[TYO];  // own-column v(q-1), v(q), v(q+1) of the output rows
     vec bq[TYO];                    // rhs of the output rows on plane q
+    T Yp[6][NR];                    // CORR: y-interpolated correction rows of the current plane p
 #pragma unroll
     for (int r = 0; r < TYV; r++) {
         um[r] = *(const vec *)(u + plane_of(z0 - 2) + ro[r]);
         uc[r] = *(const vec *)(u + plane_of(z0 - 1) + ro[r]);
+    }
+    if (CORR) {
+        T Z[4][NR], Y[6][NR];
+        zrows(z0 - 2, Z); yrows(Z, Y);
+#pragma unroll
+        for (int r = 0; r < TYV; r++) um[r] = add_vec(um[r], pe_vec(Y[1 + r]));
+        zrows(z0 - 1, Z); yrows(Z, Yp);
+#pragma unroll
+        for (int r = 0; r < TYV; r++) uc[r] = add_vec(uc[r], pe_vec(Yp[1 + r]));
     }
 #pragma unroll
     for (int r = 0; r < TYO; r++) { vm[r] = (vec)(0); vc[r] = (vec)(0); bq[r] = (vec)(0); }
@@ -284,20 +396,42 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
             up[r] = *(const vec *)(u + plane_of(p + 1) + ro[r]);
             b[r] = (vec)(0); v[r] = (vec)(0); vtail[r] = 0;
         }
+        // ---- every load of this step first ...
+        T Ra[4][NR], Rb[4][NR];  // CORR: raw coarse values under plane p+1
+        if (CORR) { raw_a(p + 1, Ra); raw_b(p + 1, Rb); }
+        vec hlo = (vec)(0), hhi = (vec)(0);
+        T elv[TYV], erv[TYV];
+#pragma unroll
+        for (int r = 0; r < TYV; r++) { elv[r] = 0; erv[r] = 0; }
         if (pin) {
 #pragma unroll
             for (int r = 0; r < TYV; r++) {
                 if (NTLOAD && r >= 1 && r <= TYO) b[r] = *(const vec *)(rhs + po + ro[r]);
                 else b[r] = *(const vec *)(rhs + po + ro[r]);
             }
-            const vec hlo = *(const vec *)(pu + ro_lo);
-            const vec hhi = *(const vec *)(pu + ro_hi);
+            hlo = *(const vec *)(pu + ro_lo);
+            hhi = *(const vec *)(pu + ro_hi);
+#pragma unroll
+            for (int r = 0; r < TYV; r++) {
+                if (lane == 0) elv[r] = pu[ro[r] - 1];
+                if (lane == 63) erv[r] = pu[ro[r] + V];
+            }
+        }
+        // ---- ... then the arithmetic
+        T Yn[6][NR];  // CORR: correction rows of plane p+1 (become Yp after this step)
+        if (CORR) {
+            T Z[4][NR];
+            zfin(p + 1, Ra, Rb, Z); yrows(Z, Yn);
+#pragma unroll
+            for (int r = 0; r < TYV; r++) up[r] = add_vec(up[r], pe_vec(Yn[1 + r]));
+        }
+        if (pin) {
+            if (CORR) { hlo = add_vec(hlo, pe_vec(Yp[0])); hhi = add_vec(hhi, pe_vec(Yp[5])); }
             const bool zbp = (p == 0) || (p == g.nz - 1);
 #pragma unroll
             for (int r = 0; r < TYV; r++) {
-                T el = 0, er = 0;
-                if (lane == 0) el = pu[ro[r] - 1];
-                if (lane == 63) er = pu[ro[r] + V];
+                T el = elv[r], er = erv[r];
+                if (CORR) { el = el + pe_left(Yp[1 + r]); er = er + pe_right(Yp[1 + r]); }
                 const T xm = from_prev_lane(uc[r][V - 1], el);
                 const T xp = from_next_lane(uc[r][0], er);
                 const vec ym = (r > 0) ? uc[r > 0 ? r - 1 : 0] : hlo;
@@ -385,6 +519,12 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
         for (int r = 0; r < TYV; r++) { um[r] = uc[r]; uc[r] = up[r]; }
 #pragma unroll
         for (int r = 0; r < TYO; r++) { vm[r] = vc[r]; vc[r] = vp[r]; bq[r] = b[r + 1]; }
+        if (CORR) {
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+#pragma unroll
+                for (int m = 0; m < NR; m++) Yp[j][m] = Yn[j][m];
+        }
     }
 }
 
@@ -487,15 +627,45 @@ void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, con
     const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
 #define MG_J2(TPR) \
     do { \
-        if (damped) { if (nt) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz); \
-                      else hipLaunchKernelGGL((k_jacobi2<T, TPR, true, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz); } \
-        else { if (nt) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz); \
-               else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz); } \
+        if (damped) { if (nt) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
+                      else hipLaunchKernelGGL((k_jacobi2<T, TPR, true, false, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); } \
+        else { if (nt) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
+               else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, false, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); } \
     } while (0)
     if (tpr == 256) MG_J2(256); else if (tpr == 128) MG_J2(128); else MG_J2(64);
 #undef MG_J2
 }
 
+// prolong-add + two Jacobi sweeps in one pass: out = J(J(u + P coarse))
+template <typename T>
+bool jacobi2_corr_ok(const Geom &gf, const Geom &gc)
+{
+    return jacobi2_ok<T>(gf) && gc.dim == 3 && gf.nx == 2 * gc.nx - 1 && gf.ny == 2 * gc.ny - 1 &&
+           gf.nz == 2 * gc.nz - 1 && gc.gz0 == 0 && gc.gnz == gc.nz;
+}
+
+template <typename T>
+void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u,
+                         const T *coarse, const T *rhs, T *out)
+{
+    constexpr int V = VecOf<T>::V;
+    const int tpr = (g.nx - 1) / V;
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = (g.nz + J2_ZC - 1) / J2_ZC;
+    const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
+    const bool damped = (omega != (T)1);
+#define MG_J2C(TPR) \
+    do { \
+        if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
+        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
+    } while (0)
+    if (tpr == 256) MG_J2C(256); else if (tpr == 128) MG_J2C(128); else MG_J2C(64);
+#undef MG_J2C
+}
+
+template bool jacobi2_corr_ok<double>(const Geom &, const Geom &);
+template bool jacobi2_corr_ok<float>(const Geom &, const Geom &);
+template void launch_jacobi2_corr<double>(hipStream_t, const Geom &, const Geom &, const Coef<double> &, double, const double *, const double *, const double *, double *);
+template void launch_jacobi2_corr<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, float, const float *, const float *, const float *, float *);
 template bool jacobi2_ok<double>(const Geom &);
 template bool jacobi2_ok<float>(const Geom &);
 template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *);

@@ -28,6 +28,11 @@ void launch_jacobi_fast(hipStream_t s, const Geom &g, const Coef<T> &c, T omega,
 template <typename T> bool jacobi2_ok(const Geom &g);
 template <typename T>
 void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out);
+// the same with the V-cycle's prolong-add folded in: out = J(J(u + P coarse)); u is not modified
+template <typename T> bool jacobi2_corr_ok(const Geom &gf, const Geom &gc);
+template <typename T>
+void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u,
+                         const T *coarse, const T *rhs, T *out);
 // out-of-place colour half-sweep (the other colour is copied): red u->tmp, black tmp->u
 template <typename T>
 void launch_rb_fast(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, const T *u, const T *rhs, T *out);

@@ -510,8 +510,21 @@ bool Solver::can_skip_zeroing(int level) const
            fast_path_ok<T>(lv_[level].g);
 }
 
+// true when the V-cycle's prolong-add into `level` can be folded into the first post-smoothing pair
+// (k_jacobi2<CORR>): out = J(J(u + P e)) without ever storing u + P e
 template <typename T>
-int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero)
+bool Solver::can_fold_prolong(int level) const
+{
+    static const bool enabled = [] { const char *e = getenv("MG_FUSED_PROLONG"); return !(e && e[0] == '0'); }();
+    return enabled && d_.smoother == MG_SMOOTH_JACOBI && d_.nu_post >= 2 && level + 1 < d_.levels &&
+           lv_[level].present && !lv_[level].dist && lv_[level + 1].present && !lv_[level + 1].dist &&
+           jacobi2_corr_ok<T>(lv_[level].g, lv_[level + 1].g);
+}
+
+// corr_level >= 0: x is still missing the coarse-grid correction P u_{corr_level}; the first fused
+// pair applies it on the fly (caller checked can_fold_prolong)
+template <typename T>
+int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero, int corr_level)
 {
     Level &L = lv_[level];
     Coef<T> c = coef_of<T>(L);
@@ -529,7 +542,11 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
         for (int s = 0; s < sweeps; s++) {
             if (!L.dist && !(x_zero && s == 0) && s + 1 < sweeps && jacobi2_ok<T>(L.g)) {
                 // two sweeps in one pass over HBM; the pair lands in TMP like a single sweep would
-                launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level));
+                if (s == 0 && corr_level >= 0)
+                    launch_jacobi2_corr<T>(stream_, L.g, lv_[corr_level].g, c, (T)d_.omega, ptr<T>(ax, level),
+                                           ptr<T>(ax, corr_level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level));
+                else
+                    launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level));
                 std::swap(L.base[ax], L.base[MG_ARR_TMP]);
                 s++;
                 continue;
@@ -576,7 +593,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
     if (prof) {
         MG_HIP(hipEventRecord(prof_ev_[prof_used_ + 1], stream_));
         prof_used_ += 2;
-        prof_sweeps_ += sweeps;
+        prof_kind_.push_back(corr_level >= 0 ? sweeps : -sweeps);  // > 0: segment also carries the prolongation
     }
     MG_HIP(hipGetLastError());
     return MG_OK;
@@ -821,6 +838,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
 {
     const int L = d_.levels;
     const bool mine = lv_[l].present;
+    bool fold = false;  // prolong-add folded into the post-smoothing pair
     if (l == L - 1) return coarse_level_t<T>(l, MG_ARR_U, MG_ARR_RHS);
     // fused residual + full weighting when both levels live whole on this rank
     const bool fuse_rr = mine && d_.restriction == MG_RESTRICT_FULLW && !lv_[l].dist && lv_[l + 1].present &&
@@ -857,9 +875,10 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         const bool skip0 = can_skip_zeroing<T>(l + 1);
         if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
         MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
-        MG_TRY(prolong_t<T>(l + 1, 1, MG_ARR_U, MG_ARR_U));
+        fold = can_fold_prolong<T>(l);
+        if (!fold) MG_TRY(prolong_t<T>(l + 1, 1, MG_ARR_U, MG_ARR_U));
     }
-    if (mine) MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS));
+    if (mine) MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS, false, fold ? l + 1 : -1));
     return MG_OK;
 }
 
@@ -1010,6 +1029,7 @@ int Solver::profile_begin()
     profiling_ = true;
     prof_used_ = 0;
     prof_sweeps_ = 0;
+    prof_kind_.clear();
     return MG_OK;
 }
 
@@ -1019,13 +1039,23 @@ int Solver::profile_end(double *ms, int *sweeps)
     MG_HIP(hipStreamSynchronize(stream_));
     profiling_ = false;
     double tot = 0;
+    prof_sweeps_ = 0; prof_fused_ms_ = 0; prof_fused_sweeps_ = 0;
     for (size_t i = 0; i + 1 < prof_used_; i += 2) {
         float f = 0;
         MG_HIP(hipEventElapsedTime(&f, prof_ev_[i], prof_ev_[i + 1]));
-        tot += f;
+        const int k = prof_kind_[i / 2];
+        if (k > 0) { prof_fused_ms_ += f; prof_fused_sweeps_ += k; }
+        else { tot += f; prof_sweeps_ += -k; }
     }
     if (ms) *ms = tot;
     if (sweeps) *sweeps = prof_sweeps_;
+    return MG_OK;
+}
+
+int Solver::profile_fused(double *ms, int *sweeps) const
+{
+    if (ms) *ms = prof_fused_ms_;
+    if (sweeps) *sweeps = prof_fused_sweeps_;
     return MG_OK;
 }
 

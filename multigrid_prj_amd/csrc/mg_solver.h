@@ -73,6 +73,7 @@ public:
     int timer_stop(double *ms);
     int profile_begin();
     int profile_end(double *ms, int *sweeps);
+    int profile_fused(double *ms, int *sweeps) const;
     size_t device_bytes() const { return bytes_; }
 
     const mg_desc &desc() const { return d_; }
@@ -83,7 +84,9 @@ private:
     template <typename T> T *ptr(int which, int level) const;  // local plane 0
     // x_zero: the caller knows x == 0 (fresh coarse-level guess): the first Jacobi sweep of a
     // fast-path level then skips reading x (and the caller skips the memset)
-    template <typename T> int smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero = false);
+    template <typename T> int smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero = false,
+                                       int corr_level = -1);
+    template <typename T> bool can_fold_prolong(int level) const;
     template <typename T> bool can_skip_zeroing(int level) const;
     template <typename T> int residual_t(int level, int ax, int ar, int arr_r, bool want_norm);
     template <typename T> int sumsq_t(int level, int arr);
@@ -152,6 +155,9 @@ private:
     std::vector<hipEvent_t> prof_ev_;
     size_t prof_used_ = 0;
     int prof_sweeps_ = 0;
+    std::vector<int> prof_kind_;   // per event pair: -sweeps (plain) or +sweeps (carries the prolongation)
+    double prof_fused_ms_ = 0;
+    int prof_fused_sweeps_ = 0;
 };
 
 }  // namespace mg

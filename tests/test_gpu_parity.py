@@ -175,6 +175,11 @@ VC = [
     dict(dim=3, n=65, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW),
     dict(dim=3, n=33, levels=3, dtype=capi.MG_F32, smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW),
     dict(dim=2, n=65, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_RBGS, omega=1.0, restriction=capi.RESTRICT_FULLW),
+    # grids wide enough for the fused kernels (double sweep, residual+restriction, and the
+    # prolongation folded into the post-smoothing pair) on one, two and two levels respectively
+    dict(dim=3, n=129, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW),
+    dict(dim=3, n=257, levels=5, dtype=capi.MG_F64, smoother=capi.SMOOTH_JACOBI, omega=0.8, restriction=capi.RESTRICT_INJECT),
+    dict(dim=3, n=257, levels=5, dtype=capi.MG_F32, smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW),
     # anisotropic eps with k ~ log4(1/eps) semi-coarsenings followed by standard ones:
     # eps = 0.01, k = 3 (coarsest 9 x 3 x 3... one-workgroup solve) and eps = 0.25, k = 1 with a coarsest
     # grid too big for one workgroup (33 x 33 x 65: swept with the regular kernels)
