@@ -143,6 +143,7 @@ __global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
                 const vec yp = (r < RY - 1) ? cc[r < RY - 1 ? r + 1 : 0] : hhi;
                 const bool rb = zb || ybnd[r];
                 vec res;
+                T num[V], quo[V];
 #pragma unroll
                 for (int e = 0; e < V; e++) {
                     const T left = (e == 0) ? xm : cc[r][e > 0 ? e - 1 : 0];
@@ -156,17 +157,25 @@ __global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
                     sum += c.cx * right;
                     sum += c.cy * yp[e];
                     sum += c.cz * zp[r][e];
-                    if (OP == OP_JACOBI) {
-                        T jac = (b[r][e] - sum) / c.cd;
-                        if (DAMPED) jac = cc[r][e] + omega * (jac - cc[r][e]);
-                        res[e] = bnd ? b[r][e] : jac;
-                    } else if (OP == OP_RB) {
-                        const T gs = (b[r][e] - sum) / c.cd;
-                        const bool mine = ((x0 + e + yb + r + gz) & 1) == colour;
-                        res[e] = mine ? (bnd ? b[r][e] : gs) : cc[r][e];
-                    } else {
+                    if (OP == OP_RESIDUAL) {
                         if (bnd) sum = (T)1 * cc[r][e];
                         res[e] = b[r][e] - sum;
+                    }
+                    num[e] = b[r][e] - sum;
+                }
+                if (OP != OP_RESIDUAL) {
+                    div_cd_n<T, V>(num, quo, c);
+#pragma unroll
+                    for (int e = 0; e < V; e++) {
+                        const bool bnd = rb || (x0 + e == 0) || (x0 + e == g.nx - 1);
+                        if (OP == OP_JACOBI) {
+                            T jac = quo[e];
+                            if (DAMPED) jac = cc[r][e] + omega * (jac - cc[r][e]);
+                            res[e] = bnd ? b[r][e] : jac;
+                        } else {
+                            const bool mine = ((x0 + e + yb + r + gz) & 1) == colour;
+                            res[e] = mine ? (bnd ? b[r][e] : quo[e]) : cc[r][e];
+                        }
                     }
                 }
                 if (xin && yin[r]) {
@@ -437,6 +446,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                 const vec ym = (r > 0) ? uc[r > 0 ? r - 1 : 0] : hlo;
                 const vec yp = (r < TYV - 1) ? uc[r < TYV - 1 ? r + 1 : 0] : hhi;
                 const bool rb = zbp || ybnd[r];
+                T num[V], quo[V];
 #pragma unroll
                 for (int e = 0; e < V; e++) {
                     const T left = (e == 0) ? xm : uc[r][e > 0 ? e - 1 : 0];
@@ -448,7 +458,12 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                     sum += c.cx * right;
                     sum += c.cy * yp[e];
                     sum += c.cz * up[r][e];
-                    T jac = (b[r][e] - sum) / c.cd;
+                    num[e] = b[r][e] - sum;
+                }
+                div_cd_n<T, V>(num, quo, c);
+#pragma unroll
+                for (int e = 0; e < V; e++) {
+                    T jac = quo[e];
                     if (DAMPED) jac = uc[r][e] + omega * (jac - uc[r][e]);
                     v[r][e] = (rb || (x0 + e == 0)) ? b[r][e] : jac;
                 }
@@ -473,6 +488,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                     const vec yp = *(const vec *)&lds[sl][lr + 1][V + x0];
                     const bool rb = zbq || (y == 0) || (y == g.ny - 1);
                     vec res;
+                    T num[V], quo[V];
 #pragma unroll
                     for (int e = 0; e < V; e++) {
                         const T left = (e == 0) ? xm : vc[r][e > 0 ? e - 1 : 0];
@@ -484,7 +500,12 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                         sum += c.cx * right;
                         sum += c.cy * yp[e];
                         sum += c.cz * vp[r][e];
-                        T jac = (bq[r][e] - sum) / c.cd;
+                        num[e] = bq[r][e] - sum;
+                    }
+                    div_cd_n<T, V>(num, quo, c);
+#pragma unroll
+                    for (int e = 0; e < V; e++) {
+                        T jac = quo[e];
                         if (DAMPED) jac = vc[r][e] + omega * (jac - vc[r][e]);
                         res[e] = (rb || (x0 + e == 0)) ? bq[r][e] : jac;
                     }

@@ -81,7 +81,7 @@ __device__ __forceinline__ T point_update(const Geom &g, const Coef<T> &c, T ome
     T b = rhs[i];
     if (on_boundary(g, z, y, x)) return b;  // (b - 0) / 1
     T sum = offdiag_sum<T, DIM>(u, i, g.pitch, g.plane, c);
-    T jac = (b - sum) / c.cd;
+    T jac = div_cd<T>(b - sum, c);
     if (DAMPED) {
         T uc = u[i];
         return uc + omega * (jac - uc);
@@ -359,6 +359,94 @@ __device__ void wg_gs_lex(const Geom &g, const Coef<T> &c, T *u, const T *rhs)
     }
 }
 
+
+// ---------------------------------------------------------------- lexicographic GS, 2-D, row threads
+// The two Gauss-Seidel pre-sweeps of every outer iteration (main.cpp:85,95) on the FINE grid.
+// Same anti-diagonal wavefront as wg_gs_lex, organised so that the serial chain of nx+ny-1 steps
+// never waits on memory: thread y owns row y and at step d updates x = d - y;
+//   new u(y, x-1)  is its own previous result (register),
+//   new u(y-1, x)  is the previous lane's previous result (DPP wave_shr:1; across waves through
+//                  a two-slot LDS mailbox),
+//   old u(y+1, x), old u(y, x+1) and rhs(y, x) are not on the chain and are fetched PF steps
+//                  ahead (their stores happen >= PF+1 barriers after the loads have completed).
+// One barrier per step with only ceil(ny/64) waves resident. Inputs and expression order per
+// point are those of point_update => bit-identical to the serial loop (solvers.hpp:33-48).
+template <typename T>
+__device__ __forceinline__ T gs_prev_lane(T v, T edge);
+template <>
+__device__ __forceinline__ float gs_prev_lane<float>(float v, float edge)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+template <>
+__device__ __forceinline__ double gs_prev_lane<double>(double v, double edge)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <typename T, int PF>
+__global__ __launch_bounds__(SWG) void k_gs_lex2d_rows(Geom g, Coef<T> c, int sweeps, T *u, const T *rhs)
+{
+    __shared__ T mail[2][SWG / 64];
+    const int y = threadIdx.x, lane = y & 63, wv = y >> 6;
+    const int nx = g.nx, ny = g.ny;
+    const bool rowin = y < ny;
+    const bool rowb = (y == 0) || (y == ny - 1);
+    const long long ro = (long long)min(y, ny - 1) * g.pitch;
+    const long long rdn = (long long)min(y + 1, ny - 1) * g.pitch;  // the row below: still old when read
+    const int nd = nx + ny - 1;                                      // anti-diagonals
+    for (int s = 0; s < sweeps; s++) {
+        T pb[PF], pdn[PF], prt[PF];
+        // unconditional (clamped) loads: with loads under a branch the compiler cannot count how
+        // many younger ones are in flight and falls back to s_waitcnt vmcnt(0) every PF steps
+        auto fetch = [&](int d, T &b, T &dn, T &rt) {
+            const int x = min(max(d - y, 0), nx - 1);
+            b = rhs[ro + x];
+            dn = u[rdn + x];
+            rt = u[ro + min(x + 1, nx - 1)];
+        };
+#pragma unroll
+        for (int j = 0; j < PF; j++) fetch(j, pb[j], pdn[j], prt[j]);
+        T mine = 0;  // new u(y, x-1)
+        T pub = 0;   // what this thread produced at the previous step: new u(y, x) of step d-1
+        for (int d0 = 0; d0 < nd; d0 += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                const int d = d0 + j, x = d - y;  // steps past nd-1 find every thread out of range
+                T from_wave = 0;
+                if (lane == 0 && wv > 0) from_wave = mail[(d + 1) & 1][wv - 1];
+                const T upnew = gs_prev_lane<T>(pub, from_wave);
+                T val = pub;
+                if (rowin && x >= 0 && x < nx) {
+                    if (rowb || x == 0 || x == nx - 1) {
+                        val = pb[j];  // Dirichlet row of the matrix: (b - 0) / 1
+                    } else {
+                        T sum = 0;
+                        sum += c.cy * upnew;
+                        sum += c.cx * mine;
+                        sum += c.cx * prt[j];
+                        sum += c.cy * pdn[j];
+                        val = div_cd<T>(pb[j] - sum, c);
+                    }
+                    u[ro + x] = val;
+                    mine = val;
+                }
+                pub = val;
+                if (lane == 63) mail[d & 1][wv] = val;
+                fetch(d + PF, pb[j], pdn[j], prt[j]);
+                // LDS-only release/acquire around the barrier: a full __syncthreads() would also
+                // drain vmcnt, i.e. wait for the prefetches just issued, every step
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            }
+        }
+        __syncthreads();  // this sweep's stores are the next sweep's old values
+    }
+}
+
 template <typename T, int DIM>
 __device__ double wg_residual_sumsq(const Geom &g, const Coef<T> &c, const T *u, const T *rhs,
                                     double *sh)
@@ -542,7 +630,7 @@ __global__ __launch_bounds__(SWG) void k_coarse_solve_lds(Geom g, Coef<T> c, T o
                     T b = sr[i], r = b;
                     if (!pbnd[k]) {
                         T sum = offdiag_sum<T, DIM>(sx, i, gl.pitch, gl.plane, c);
-                        T jac = (b - sum) / c.cd;
+                        T jac = div_cd<T>(b - sum, c);
                         r = damped ? sx[i] + omega * (jac - sx[i]) : jac;
                     }
                     st[i] = r;
@@ -601,6 +689,200 @@ __global__ __launch_bounds__(SWG) void k_coarse_solve_lds(Geom g, Coef<T> c, T o
     }
 }
 
+
+// ---------------------------------------------------------------- LDS coarse solver, Jacobi
+// The reference's dominant loop (Solver::Solve with a Jacobi smoother on the coarsest level,
+// solvers.hpp:324-342: ~1900 iterations per cycle at 65^2) restructured around what an
+// iteration really needs:
+//  * a thread owns a run of SEG consecutive interior x-points of one row: its own values and right-hand
+//    sides stay in registers, x-neighbours inside the run are registers too, so an iteration
+//    reads 2 (4 in 3-D) row neighbours per point + the 2 run ends from LDS instead of 11 (15);
+//  * residual(x_k) and the sweep x_k -> x_{k+1} read the same neighbours: one pass computes the
+//    residual's sum of squares AND the tentative next iterate, which is stored to the other LDS
+//    buffer before the reduction barrier -- ONE barrier per iteration; if the norm test says
+//    stop, the tentative iterate is simply dropped;
+//  * the norm test sqrt(nr/nb) > tol is decided by nr vs tol^2 nb whenever they differ by more
+//    than 1e-9 relative (the exact expression cannot disagree there) and by the exact expression
+//    otherwise, so the stopping iteration is the reference's;
+//  * the wave reduction runs on DPP (no LDS traffic).
+// Per-point arithmetic is that of wg_jacobi / the residual: x is bit-identical to the generic
+// loop after the same number of iterations (tests/test_gpu_parity.py::test_coarse_solver).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shifted(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes, returned to every lane (fixed order: deterministic)
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+    v += dpp_shifted<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_shifted<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_shifted<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_shifted<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row's sum
+    v += dpp_shifted<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_shifted<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+template <typename T, int DIM, int SEG>
+__global__ __launch_bounds__(SWG) void k_coarse_jacobi_rows(Geom g, Coef<T> c, T omega, T *x, const T *rhs,
+                                                            int maxit, double tol, int fixed, CoarseOut *out)
+{
+    // Threads own INTERIOR points only, in full runs of SEG (the launcher checks (nx-2) % SEG == 0):
+    // the iteration body has no predicates and no boundary selects, so the SEG points of a thread
+    // are one basic block whose LDS loads and arithmetic interleave. The Dirichlet nodes change
+    // once (x <- b in the first sweep) and are handled by a strided loop in the first two trips,
+    // which also leaves b in both LDS buffers; from then on their residual b - 1*b is a constant.
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ double part[2][SWG / 64];
+    const int nx = g.nx, ny = g.ny, npl = nx * ny, total = npl * g.nz;
+    T *cur = reinterpret_cast<T *>(smem_raw);
+    T *nxt = cur + total;
+    const int nseg = (nx - 2) / SEG;
+    const int irows = (ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
+    const int nthr = (int)blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;
+    const bool active = tid < nseg * irows;
+    const int row = active ? tid / nseg : 0, seg = active ? tid - row * nseg : 0;
+    const int z = (DIM == 3) ? 1 + row / (ny - 2) : 0;
+    const int y = 1 + ((DIM == 3) ? row % (ny - 2) : row);
+    const int x0 = 1 + seg * SEG;
+    const int i0 = (z * ny + y) * nx + x0;  // dense LDS index of the first own point
+    const bool damped = (omega != (T)1);
+    auto dense_to_global = [&](int q) -> long long {
+        const int zz = q / npl, rem = q - zz * npl, yy = rem / nx, xx = rem - yy * nx;
+        return lidx(g, zz, yy, xx);
+    };
+    auto is_bnd = [&](int q) -> bool {
+        const int zz = q / npl, rem = q - zz * npl, yy = rem / nx, xx = rem - yy * nx;
+        return xx == 0 || xx == nx - 1 || yy == 0 || yy == ny - 1 || (DIM == 3 && (zz == 0 || zz == g.nz - 1));
+    };
+    // stage x into LDS; own values and right-hand sides into registers
+    double sqb = 0.;
+    for (int q = tid; q < total; q += nthr) {
+        const long long gi = dense_to_global(q);
+        cur[q] = x[gi];
+        const double t = (double)rhs[gi];
+        sqb += t * t;
+    }
+    T xv[SEG], bv[SEG];
+#pragma unroll
+    for (int k = 0; k < SEG; k++) {
+        xv[k] = 0; bv[k] = 0;
+        if (active) {
+            const long long gi = lidx(g, z, y, x0 + k);
+            xv[k] = x[gi]; bv[k] = rhs[gi];
+        }
+    }
+    int parity = 0;
+    auto block_sum = [&](double v) -> double {  // one barrier; also publishes the LDS stores made before it
+        v = wave_sum_dpp(v);
+        if (lane == 0) part[parity][wv] = v;
+        __syncthreads();
+        double sum = 0;
+        for (int w = 0; w < nw; w++) sum += part[parity][w];
+        parity ^= 1;
+        return sum;
+    };
+    const double nb = block_sum(sqb);  // refresh_normalization_constant, solvers.hpp:244-254
+    // sqrt(nr / nb) > tol, decided without the division and the root when it is not close
+    const double t2 = tol * tol * nb;
+    const bool pretest = (tol > 0) && (t2 > 1e-290) && (t2 < 1e290);
+    const double t2_hi = t2 * (1. + 1e-9), t2_lo = t2 * (1. - 1e-9);
+    auto above_tol = [&](double nr) -> bool {
+        if (pretest) {
+            if (nr > t2_hi) return true;
+            if (nr < t2_lo) return false;
+        }
+        return sqrt(nr / nb) > tol;  // NaN (zero rhs) compares false, like the reference
+    };
+    int iters = 0, flag = 0, counter = maxit;
+    double nr, bnd_sq = 0.;  // bnd_sq: this thread's share of the Dirichlet nodes' r^2 (constant from trip 2 on)
+    for (;;) {
+        double sq = 0.;
+        if (iters < 2) {  // uniform. Dirichlet nodes: r = b - 1*x, x <- b
+            bnd_sq = 0.;
+            for (int q = tid; q < total; q += nthr) {
+                if (is_bnd(q)) {
+                    const T bq = rhs[dense_to_global(q)];
+                    const T res = bq - (T)1 * cur[q];
+                    bnd_sq += (double)res * (double)res;
+                    nxt[q] = bq;
+                }
+            }
+        }
+        sq = bnd_sq;
+        T nv[SEG];
+        if (active) {
+            const T el = cur[i0 - 1], er = cur[i0 + SEG];
+            T ym[SEG], yp[SEG], zm[SEG], zp[SEG], num[SEG], quo[SEG];
+#pragma unroll
+            for (int k = 0; k < SEG; k++) {
+                ym[k] = cur[i0 + k - nx]; yp[k] = cur[i0 + k + nx];
+                zm[k] = 0; zp[k] = 0;
+                if (DIM == 3) { zm[k] = cur[i0 + k - npl]; zp[k] = cur[i0 + k + npl]; }
+            }
+#pragma unroll
+            for (int k = 0; k < SEG; k++) {
+                const T left = (k == 0) ? el : xv[k > 0 ? k - 1 : 0];
+                const T right = (k == SEG - 1) ? er : xv[k < SEG - 1 ? k + 1 : 0];
+                T fs = 0;  // residual row, diagonal included (solvers.hpp:269-271)
+                if (DIM == 3) fs += c.cz * zm[k];
+                fs += c.cy * ym[k];
+                fs += c.cx * left;
+                fs += c.cd * xv[k];
+                fs += c.cx * right;
+                fs += c.cy * yp[k];
+                if (DIM == 3) fs += c.cz * zp[k];
+                const T res = bv[k] - fs;
+                sq += (double)res * (double)res;
+                T os = 0;  // Jacobi row, off-diagonals only (solvers.hpp:72-79)
+                if (DIM == 3) os += c.cz * zm[k];
+                os += c.cy * ym[k];
+                os += c.cx * left;
+                os += c.cx * right;
+                os += c.cy * yp[k];
+                if (DIM == 3) os += c.cz * zp[k];
+                num[k] = bv[k] - os;
+            }
+            div_cd_n<T, SEG>(num, quo, c);
+#pragma unroll
+            for (int k = 0; k < SEG; k++) {
+                nv[k] = damped ? xv[k] + omega * (quo[k] - xv[k]) : quo[k];
+                nxt[i0 + k] = nv[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SEG; k++) nv[k] = 0;
+        }
+        nr = block_sum(sq);
+        bool go;
+        if (fixed) go = iters < maxit;
+        else if (above_tol(nr)) { go = counter > 0; if (!go) flag = 1; }
+        else go = false;
+        if (!go) break;  // uniform: every thread sees the same nr
+        counter -= 1;
+        iters++;
+#pragma unroll
+        for (int k = 0; k < SEG; k++) xv[k] = nv[k];
+        T *t = cur; cur = nxt; nxt = t;
+    }
+    // cur holds the final iterate, Dirichlet nodes included
+    for (int q = tid; q < total; q += nthr) x[dense_to_global(q)] = cur[q];
+    if (tid == 0) {
+        out->iters = iters;
+        out->flag = flag;
+        out->relres = sqrt(nr / nb);
+        out->sumsq_rhs = nb;
+        out->sumsq_r = nr;
+    }
+}
+
 inline dim3 grid_for(int nx, int ny, int nz)
 {
     return dim3((nx + BX - 1) / BX, (ny + BY - 1) / BY, nz);
@@ -645,7 +927,15 @@ void launch_rbgs_colour(hipStream_t s, const Geom &g, const Coef<T> &c, int colo
 template <typename T>
 void launch_gs_lex(hipStream_t s, const Geom &g, const Coef<T> &c, int sweeps, T *u, const T *rhs)
 {
+    static const bool rows = [] { const char *e = getenv("MG_GS_ROWS"); return !(e && e[0] == '0'); }();
     if (g.dim == 3) hipLaunchKernelGGL((k_gs_lex<T, 3>), dim3(1), dim3(SWG), 0, s, g, c, sweeps, u, rhs);
+    else if (rows && g.ny <= SWG && g.nx >= 3 && g.ny >= 3) {  // one thread per row
+        static const int pf = [] { const char *e = getenv("MG_GS_PF"); return e ? atoi(e) : 4; }();
+        const dim3 bl(((g.ny + 63) / 64) * 64);
+        if (pf == 16) hipLaunchKernelGGL((k_gs_lex2d_rows<T, 16>), dim3(1), bl, 0, s, g, c, sweeps, u, rhs);
+        else if (pf == 8) hipLaunchKernelGGL((k_gs_lex2d_rows<T, 8>), dim3(1), bl, 0, s, g, c, sweeps, u, rhs);
+        else hipLaunchKernelGGL((k_gs_lex2d_rows<T, 4>), dim3(1), bl, 0, s, g, c, sweeps, u, rhs);
+    }
     else hipLaunchKernelGGL((k_gs_lex<T, 2>), dim3(1), dim3(SWG), 0, s, g, c, sweeps, u, rhs);
 }
 
@@ -744,12 +1034,55 @@ static bool try_launch_coarse_lds(hipStream_t s, const Geom &g, const Coef<T> &c
     return true;
 }
 
+
+template <typename T, int DIM, int SEG>
+static bool try_launch_coarse_jacobi_rows(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, T *x,
+                                          const T *rhs, int maxit, double tol, int fixed, CoarseOut *d_out)
+{
+    const size_t total = (size_t)g.nx * g.ny * g.nz;
+    const size_t bytes = 2 * total * sizeof(T);
+    if (g.nx < 3 + SEG - 1 || (g.nx - 2) % SEG != 0) return false;  // full runs of SEG interior points only
+    const int threads = ((g.nx - 2) / SEG) * (g.ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
+    if (threads < 256 || threads > SWG || bytes > (size_t)150 * 1024) return false;
+    auto kern = k_coarse_jacobi_rows<T, DIM, SEG>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                150 * 1024) != hipSuccess) return false;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(((threads + 63) / 64) * 64), bytes, s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
+    return true;
+}
+
+template <typename T, int DIM>
+static bool try_launch_coarse_jacobi(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, T *x, const T *rhs,
+                                     int maxit, double tol, int fixed, CoarseOut *d_out)
+{
+    static const bool enabled = [] { const char *e = getenv("MG_COARSE_ROWS"); return !(e && e[0] == '0'); }();
+    if (!enabled || g.ny < 3 || (DIM == 3 && g.nz < 3)) return false;
+    // odd run lengths (consecutive threads then hit distinct LDS banks: stride 2*SEG dwords in
+    // fp64) that divide the interior width: 65^2 -> 63 = 9 x 7, 17^3 -> 15 = 3 x 5; other sizes
+    // (31, 23, 8 ... interior points per row) keep the generic LDS kernel
+    static const int pref = [] { const char *e = getenv("MG_COARSE_SEG"); return e ? atoi(e) : 0; }();
+    if (pref == 9 && try_launch_coarse_jacobi_rows<T, DIM, 9>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out)) return true;
+    if (pref == 7 && try_launch_coarse_jacobi_rows<T, DIM, 7>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out)) return true;
+    return try_launch_coarse_jacobi_rows<T, DIM, 5>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out) ||
+           try_launch_coarse_jacobi_rows<T, DIM, 7>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out) ||
+           try_launch_coarse_jacobi_rows<T, DIM, 9>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out) ||
+           try_launch_coarse_jacobi_rows<T, DIM, 3>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
+}
+
 template <typename T>
 void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, int smoother,
                          T *x, T *tmp, const T *rhs, int maxit, double tol, int fixed,
                          CoarseOut *d_out)
 {
     // LDS-resident when the three arrays fit one CU's LDS, global-memory loop otherwise
+    if (smoother == 1 && g.gz0 == 0 && g.gnz == g.nz) {  // Jacobi: the row-segment kernel
+        if (g.dim == 3 ? try_launch_coarse_jacobi<T, 3>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out)
+                       : try_launch_coarse_jacobi<T, 2>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out)) return;
+    }
     if (g.dim == 3) {
         if (try_launch_coarse_lds<T, 3, 5>(s, g, c, omega, smoother, x, rhs, maxit, tol, fixed, d_out)) return;
         hipLaunchKernelGGL((k_coarse_solve<T, 3>), dim3(1), dim3(SWG), 0, s, g, c, omega, smoother, x,

@@ -499,7 +499,10 @@ int Solver::allreduce(double *dptr, int n)
 template <typename T>
 static Coef<T> coef_of(const Level &L)
 {
-    return Coef<T>{(T)L.coef[0], (T)L.coef[1], (T)L.coef[2], (T)L.coef[3]};
+    static const bool fast_div = [] { const char *e = getenv("MG_FAST_DIV"); return !(e && e[0] == '0'); }();
+    Coef<T> c = make_coef<T>(L.coef[0], L.coef[1], L.coef[2], L.coef[3]);
+    if (!fast_div) c.win = 0;  // A/B switch: hardware division everywhere
+    return c;
 }
 
 // true when the first pre-smoothing sweep of `level` can consume an implicit zero guess

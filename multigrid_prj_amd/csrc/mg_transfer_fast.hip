@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * PBW) void k_prolong3d_fast(Geom gc, Geom gf, c
 //     rhs_c(K,J,I) = sum_{dz,dy,dx} w r(2K+dz, 2J+dy, 2I+dx),   r = rhs_f - A u  on the fly,
 // so the fine residual array is neither written nor read back (17 B instead of 41 B per fine
 // point). Lane <-> coarse column I <-> fine x-vector (2I, 2I+1 [,2I+2, 2I+3]); wave <-> coarse
-// row J (fine rows 2J-1, 2J, 2J+1); the workgroup marches the fine planes of ZCC coarse planes
+// row J (fine rows 2J-1, 2J, 2J+1); the workgroup marches the fine planes of zcc coarse planes
 // with u(z-1), u(z), u(z+1) of its three residual rows in registers. Weights are applied in
 // the oracle's order -- x (q r(x-1) + h r(x) + q r(x+1), r(x-1) from the previous lane by DPP),
 // then y, then z through a three-stage register pipeline -- so the result is bit-identical to
@@ -161,7 +161,6 @@ __device__ __forceinline__ double prev_lane(double v, double edge)
     return __hiloint2double(hi, lo);
 }
 
-constexpr int ZCC = 4;   // coarse planes per workgroup
 
 // One workgroup = CR consecutive coarse rows over their whole width: NW waves side by side in
 // x; each lane evaluates the 2*CR+1 fine residual rows those coarse rows need (neighbouring
@@ -170,7 +169,7 @@ constexpr int ZCC = 4;   // coarse planes per workgroup
 template <typename T, bool NTLOAD, int CR, bool SEMI>
 __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coef<T> c, const T *__restrict__ u,
                                                             const T *__restrict__ rhs, T *__restrict__ coarse,
-                                                            int nby, int nbz)
+                                                            int nby, int nbz, int zcc)
 {
     constexpr int V = PV<T>::V, CV = V / 2, NR = 2 * CR + 1;
     typedef typename PV<T>::vec vec;
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
     const int x0c = min(x0, gf.pitch - V);   // clamped for loads; every lane stays active
     const bool cin = ic0 + CV - 1 <= gc.nx - 2;      // owns CV real coarse columns (tail column excluded)
     const bool tail_lane = (x0 + V == gf.nx - 1);    // the lane next to the odd last fine column
-    const int K0 = bz * ZCC, K1 = min(K0 + ZCC, gc.nz);
+    const int K0 = bz * zcc, K1 = min(K0 + zcc, gc.nz);  // zcc coarse planes per workgroup
     // fine rows 2*J0-1 .. 2*J0+2*CR-1 (clamped rows only ever feed injecting boundary nodes)
     long long ro[NR];
     bool ybnd[NR];
@@ -373,15 +372,17 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
     const int ncol = gc.nx - 1;                               // coarse columns owned by lanes
     const int nw = (ncol + 64 * CV - 1) / (64 * CV);          // waves side by side in x (<= 8)
     const int nby = (gc.ny + CR - 1) / CR;
-    const int nbz = (gc.nz + ZCC - 1) / ZCC;
+    static const int zcc_env = [] { const char *e = getenv("MG_RR_ZCC"); return e ? atoi(e) : 0; }();
+    const int zcc = zcc_env > 0 ? zcc_env : 4;               // coarse planes marched per workgroup
+    const int nbz = (gc.nz + zcc - 1) / zcc;
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool nt = (size_t)gf.nz * gf.plane * sizeof(T) >= ((size_t)64 << 20);
     if (transfer_is_semi(gf, gc)) {
-        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
-        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
+        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc);
+        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc);
     } else {
-        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
-        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz);
+        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc);
+        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc);
     }
 }
 

@@ -108,13 +108,16 @@ int main(int argc, char **argv)
         } else {
             MultiGrid::mg_check(mg_get_solution(h, u.data()));
         }
-        mg_destroy(h);
     } catch (const MultiGrid::HipError &e) {
         std::cout << "Error: " << e.what() << std::endl;
+        mg_destroy(h);
         return 1;
     }
 
+    // the reference stops its clock after the iteration loop (main.cpp:114); tearing the device
+    // hierarchy down corresponds to its destructors at scope exit, after the report
     end = std::chrono::high_resolution_clock::now();
+    mg_destroy(h);
     std::chrono::duration<double> solve_time = end - start;
     std::cout << "||Solving elapsed time: " << solve_time.count() << " sec<br>" << std::endl;
     std::cout << "Tol: " << TOL << "<br>" << std::endl;

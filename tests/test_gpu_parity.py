@@ -290,6 +290,40 @@ def test_fused_double_sweep_equals_two_sweeps(n, dtype, omega):
         assert np.array_equal(s.get_array(capi.ARR_U, 0), ops.smooth(0, po.SMOOTH_JACOBI, 3, ref2, b))
 
 
+@pytest.mark.parametrize("dtype", [capi.MG_F64, capi.MG_F32])
+@pytest.mark.parametrize("n,dim", [(129, 3), (37, 3), (65, 2)])
+def test_division_by_the_diagonal_is_ieee_exact_over_the_whole_range(n, dim, dtype):
+    """The kernels divide by the constant diagonal with q = a*y, r = fma(-q, cd, a), q' = fma(r, y, q)
+    (mg_geom.h div_cd) inside an exponent window and with the hardware division outside it. With
+    u = 0 a Jacobi sweep returns rhs / cd, so right-hand sides drawn from ALL bit patterns (normal,
+    subnormal, +-0, huge, Inf, NaN) exercise both paths and the window edges; the result must have
+    the bits of the oracle's plain division (NaNs at the same places)."""
+    kw = dict(dim=dim, n=n, levels=2, dtype=dtype, length=1.0, alpha=1.0, omega=1.0)
+    s, ops, do = pair(**kw)
+    rng = np.random.default_rng(1234)
+    shape = (n, n, n) if dim == 3 else (n, n)
+    it = np.uint64 if dtype == capi.MG_F64 else np.uint32
+    with s:
+        bits = rng.integers(0, np.iinfo(it).max, size=shape, dtype=it, endpoint=True)
+        b = bits.view(s.np).copy()
+        # a band of exponents around the window edges and some exact zeros of both signs
+        flat = b.reshape(-1)
+        edge = (2.0 ** rng.integers(-1000 if dtype == capi.MG_F64 else -70, -880 if dtype == capi.MG_F64 else -50, size=flat.size // 8))
+        flat[: edge.size] = (edge * rng.uniform(1, 2, edge.size)).astype(s.np)
+        flat[edge.size: edge.size + 100] = 0.0
+        flat[edge.size + 100: edge.size + 200] = -0.0
+        u = np.zeros(shape, s.np)
+        s.set_array(capi.ARR_U, 0, u); s.set_array(capi.ARR_RHS, 0, b)
+        s.smooth(0, capi.SMOOTH_JACOBI, 1, capi.ARR_U, capi.ARR_RHS)
+        got = s.get_array(capi.ARR_U, 0)
+        with np.errstate(all="ignore"):
+            ref = ops.jacobi(0, u, b)
+        nan = np.isnan(ref)
+        assert np.array_equal(np.isnan(got), nan)
+        iv = np.int64 if dtype == capi.MG_F64 else np.int32
+        assert np.array_equal(got.view(iv)[~nan], ref.view(iv)[~nan])   # bit patterns, signed zeros included
+
+
 def test_manufactured_solution_second_order():
     """3-D accuracy check with no oracle in the loop: u* = sin sin sin, error O(h^2)."""
     errs = []
