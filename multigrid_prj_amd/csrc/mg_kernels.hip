@@ -733,7 +733,7 @@ template <typename T, int DIM, int SEG>
 __global__ __launch_bounds__(SWG) void k_coarse_jacobi_rows(Geom g, Coef<T> c, T omega, T *x, const T *rhs,
                                                             int maxit, double tol, int fixed, CoarseOut *out)
 {
-    // Threads own INTERIOR points only, in full runs of SEG (the launcher checks (nx-2) % SEG == 0):
+    // Threads own INTERIOR points only, in full runs of SEG:
     // the iteration body has no predicates and no boundary selects, so the SEG points of a thread
     // are one basic block whose LDS loads and arithmetic interleave. The Dirichlet nodes change
     // once (x <- b in the first sweep) and are handled by a strided loop in the first two trips,
@@ -743,15 +743,22 @@ __global__ __launch_bounds__(SWG) void k_coarse_jacobi_rows(Geom g, Coef<T> c, T
     const int nx = g.nx, ny = g.ny, npl = nx * ny, total = npl * g.nz;
     T *cur = reinterpret_cast<T *>(smem_raw);
     T *nxt = cur + total;
-    const int nseg = (nx - 2) / SEG;
+    const int W = nx - 2, nseg = (W + SEG - 1) / SEG;
     const int irows = (ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
     const int nthr = (int)blockDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;
     const bool active = tid < nseg * irows;
-    const int row = active ? tid / nseg : 0, seg = active ? tid - row * nseg : 0;
+    // consecutive lanes take consecutive ROWS of one run column: their LDS addresses are nx (odd)
+    // elements apart -> conflict-free for any run length. When SEG does not divide the interior
+    // width the last run is shifted left to stay full and overlaps its neighbour by ONE point
+    // (the launcher admits nothing else): both owners compute and store the same bits, only the
+    // shifted run leaves the shared point out of the norm.
+    const int seg = active ? tid / irows : 0, row = active ? tid - seg * irows : 0;
     const int z = (DIM == 3) ? 1 + row / (ny - 2) : 0;
     const int y = 1 + ((DIM == 3) ? row % (ny - 2) : row);
-    const int x0 = 1 + seg * SEG;
+    const int xs = min(seg * SEG, W - SEG);
+    const bool dup0 = (xs != seg * SEG);  // own point 0 is also the previous run's last point
+    const int x0 = 1 + xs;
     const int i0 = (z * ny + y) * nx + x0;  // dense LDS index of the first own point
     const bool damped = (omega != (T)1);
     auto dense_to_global = [&](int q) -> long long {
@@ -840,7 +847,8 @@ __global__ __launch_bounds__(SWG) void k_coarse_jacobi_rows(Geom g, Coef<T> c, T
                 fs += c.cy * yp[k];
                 if (DIM == 3) fs += c.cz * zp[k];
                 const T res = bv[k] - fs;
-                sq += (double)res * (double)res;
+                const double r2 = (double)res * (double)res;
+                sq += (k == 0 && dup0) ? 0. : r2;
                 T os = 0;  // Jacobi row, off-diagonals only (solvers.hpp:72-79)
                 if (DIM == 3) os += c.cz * zm[k];
                 os += c.cy * ym[k];
@@ -1041,9 +1049,10 @@ static bool try_launch_coarse_jacobi_rows(hipStream_t s, const Geom &g, const Co
 {
     const size_t total = (size_t)g.nx * g.ny * g.nz;
     const size_t bytes = 2 * total * sizeof(T);
-    if (g.nx < 3 + SEG - 1 || (g.nx - 2) % SEG != 0) return false;  // full runs of SEG interior points only
-    const int threads = ((g.nx - 2) / SEG) * (g.ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
-    if (threads < 256 || threads > SWG || bytes > (size_t)150 * 1024) return false;
+    const int W = g.nx - 2, nseg = (W + SEG - 1) / SEG;
+    if (W < SEG || nseg * SEG - W > 1) return false;  // full runs, at most one shared point per row
+    const int threads = nseg * (g.ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
+    if (threads < 128 || threads > SWG || bytes > (size_t)150 * 1024) return false;
     auto kern = k_coarse_jacobi_rows<T, DIM, SEG>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -1061,16 +1070,27 @@ static bool try_launch_coarse_jacobi(hipStream_t s, const Geom &g, const Coef<T>
 {
     static const bool enabled = [] { const char *e = getenv("MG_COARSE_ROWS"); return !(e && e[0] == '0'); }();
     if (!enabled || g.ny < 3 || (DIM == 3 && g.nz < 3)) return false;
-    // odd run lengths (consecutive threads then hit distinct LDS banks: stride 2*SEG dwords in
-    // fp64) that divide the interior width: 65^2 -> 63 = 9 x 7, 17^3 -> 15 = 3 x 5; other sizes
-    // (31, 23, 8 ... interior points per row) keep the generic LDS kernel
+    // run length, in measured order of preference (MI355X, one CU): 65^2 -> 8 (504 threads, two
+    // waves per SIMD: 52 ms for BASELINE config 1 against 55 ms with 7 and 64 ms with 9);
+    // 17^3 -> 5 (675 threads; 8 is 2 % slower per V-cycle at 513^3)
     static const int pref = [] { const char *e = getenv("MG_COARSE_SEG"); return e ? atoi(e) : 0; }();
-    if (pref == 9 && try_launch_coarse_jacobi_rows<T, DIM, 9>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out)) return true;
-    if (pref == 7 && try_launch_coarse_jacobi_rows<T, DIM, 7>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out)) return true;
-    return try_launch_coarse_jacobi_rows<T, DIM, 5>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out) ||
-           try_launch_coarse_jacobi_rows<T, DIM, 7>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out) ||
-           try_launch_coarse_jacobi_rows<T, DIM, 9>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out) ||
-           try_launch_coarse_jacobi_rows<T, DIM, 3>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
+    const int W = g.nx - 2, irows = (g.ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
+    const int order2[5] = {pref, 8, 4, 7, 5}, order3[5] = {pref, 5, 4, 8, 7};
+    int best = 0;
+    for (int seg : (DIM == 3 ? order3 : order2)) {
+        if (seg != 4 && seg != 5 && seg != 7 && seg != 8) continue;
+        const int nseg = (W + seg - 1) / seg, threads = nseg * irows;
+        if (W < seg || nseg * seg - W > 1 || threads < 128 || threads > SWG) continue;
+        best = seg;
+        break;
+    }
+    switch (best) {
+    case 4: return try_launch_coarse_jacobi_rows<T, DIM, 4>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
+    case 5: return try_launch_coarse_jacobi_rows<T, DIM, 5>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
+    case 7: return try_launch_coarse_jacobi_rows<T, DIM, 7>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
+    case 8: return try_launch_coarse_jacobi_rows<T, DIM, 8>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
+    default: return false;  // other widths keep the generic LDS kernel
+    }
 }
 
 template <typename T>
