@@ -242,7 +242,11 @@ constexpr int J2_TYO = 2, J2_ZC = 16;
 // prolongation's own expression tree -- z midpoints, then y, then x, each 0.5*(a+b) -- from the
 // coarse values of 4 coarse rows per plane (own columns + DPP neighbours, L1/L2-hot), so
 // u + P e has exactly the bits k_prolong3d_fast<ADD> would have stored.
-template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false>
+// RB: the same pipeline runs ONE red-black Gauss-Seidel sweep instead of two Jacobi sweeps: phase 1
+// is the red half-sweep (red points updated from u, black points copied), phase 2 the black
+// half-sweep on the plane behind (black points updated from phase 1's values, red points
+// copied): out = RB(u) in one pass over HBM instead of two (k_sweep3d<OP_RB> twice).
+template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false>
 __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
                                                  const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz,
                                                  const T *__restrict__ coarse, Geom gc)
@@ -466,6 +470,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                     T jac = quo[e];
                     if (DAMPED) jac = uc[r][e] + omega * (jac - uc[r][e]);
                     v[r][e] = (rb || (x0 + e == 0)) ? b[r][e] : jac;
+                    if (RB && (((x0 + e + y0 - 1 + r + p) & 1) != 0)) v[r][e] = uc[r][e];  // not red: unchanged
                 }
                 if (tail) vtail[r] = rhs[po + ro[r] + V];  // first sweep on the Dirichlet column: v = rhs
             }
@@ -508,6 +513,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                         T jac = quo[e];
                         if (DAMPED) jac = vc[r][e] + omega * (jac - vc[r][e]);
                         res[e] = (rb || (x0 + e == 0)) ? bq[r][e] : jac;
+                        if (RB && (((x0 + e + y + q) & 1) == 0)) res[e] = vc[r][e];  // not black: unchanged
                     }
                     __builtin_nontemporal_store(res, (vec *)(out + qo + ro[lr]));
                     if (tailwave && lane >= 56) {
@@ -656,6 +662,37 @@ void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, con
     if (tpr == 256) MG_J2(256); else if (tpr == 128) MG_J2(128); else MG_J2(64);
 #undef MG_J2
 }
+
+// one red-black Gauss-Seidel sweep (both colours) in one pass: out = RB(u)
+template <typename T>
+bool rb_fused_ok(const Geom &g)
+{
+    static const bool enabled = [] { const char *e = getenv("MG_FUSED_RB"); return !(e && e[0] == '0'); }();
+    return enabled && jacobi2_ok<T>(g);
+}
+
+// coarse != nullptr: the sweep reads u + P coarse (prolong-add folded in, like launch_jacobi2_corr)
+template <typename T>
+void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs, T *out,
+                     const T *coarse, const Geom &gc)
+{
+    constexpr int V = VecOf<T>::V;
+    const int tpr = (g.nx - 1) / V;
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = (g.nz + J2_ZC - 1) / J2_ZC;
+    const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
+#define MG_RB2(TPR) \
+    do { \
+        if (coarse) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, coarse, gc); \
+        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
+    } while (0)
+    if (tpr == 256) MG_RB2(256); else if (tpr == 128) MG_RB2(128); else MG_RB2(64);
+#undef MG_RB2
+}
+
+template bool rb_fused_ok<double>(const Geom &);
+template bool rb_fused_ok<float>(const Geom &);
+template void launch_rb_fused<double>(hipStream_t, const Geom &, const Coef<double> &, const double *, const double *, double *, const double *, const Geom &);
+template void launch_rb_fused<float>(hipStream_t, const Geom &, const Coef<float> &, const float *, const float *, float *, const float *, const Geom &);
 
 // prolong-add + two Jacobi sweeps in one pass: out = J(J(u + P coarse))
 template <typename T>

@@ -33,6 +33,11 @@ template <typename T> bool jacobi2_corr_ok(const Geom &gf, const Geom &gc);
 template <typename T>
 void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u,
                          const T *coarse, const T *rhs, T *out);
+// one whole red-black sweep in one pass (same gate as the fused double Jacobi sweep)
+template <typename T> bool rb_fused_ok(const Geom &g);
+template <typename T>
+void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs, T *out,
+                     const T *coarse, const Geom &gc);
 // out-of-place colour half-sweep (the other colour is copied): red u->tmp, black tmp->u
 template <typename T>
 void launch_rb_fast(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, const T *u, const T *rhs, T *out);

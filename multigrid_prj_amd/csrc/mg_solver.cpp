@@ -519,7 +519,9 @@ template <typename T>
 bool Solver::can_fold_prolong(int level) const
 {
     static const bool enabled = [] { const char *e = getenv("MG_FUSED_PROLONG"); return !(e && e[0] == '0'); }();
-    return enabled && d_.smoother == MG_SMOOTH_JACOBI && d_.nu_post >= 2 && level + 1 < d_.levels &&
+    const bool sm = (d_.smoother == MG_SMOOTH_JACOBI && d_.nu_post >= 2) ||
+                    (d_.smoother == MG_SMOOTH_RBGS && d_.nu_post >= 1 && rb_fused_ok<T>(lv_[level].g));
+    return enabled && sm && level + 1 < d_.levels &&
            lv_[level].present && !lv_[level].dist && lv_[level + 1].present && !lv_[level + 1].dist &&
            jacobi2_corr_ok<T>(lv_[level].g, lv_[level + 1].g);
 }
@@ -569,6 +571,13 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
         break;
     case MG_SMOOTH_RBGS:
         for (int s = 0; s < sweeps; s++) {
+            if (!L.dist && rb_fused_ok<T>(L.g)) {  // both colours in one pass over HBM; the sweep lands in TMP
+                const bool corr = (s == 0 && corr_level >= 0);
+                launch_rb_fused<T>(stream_, L.g, c, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
+                                   corr ? ptr<T>(ax, corr_level) : (const T *)nullptr, lv_[corr ? corr_level : level].g);
+                std::swap(L.base[ax], L.base[MG_ARR_TMP]);
+                continue;
+            }
             if (fast_path_ok<T>(L.g)) {  // vectorised, out of place: red x -> tmp, black tmp -> x
                 T *px = ptr<T>(ax, level), *pr = ptr<T>(ar, level), *pt = ptr<T>(MG_ARR_TMP, level);
                 MG_TRY(overlapped(level, ax, [&](const Geom &gs, long long off) {

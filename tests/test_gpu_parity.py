@@ -180,6 +180,9 @@ VC = [
     dict(dim=3, n=129, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW),
     dict(dim=3, n=257, levels=5, dtype=capi.MG_F64, smoother=capi.SMOOTH_JACOBI, omega=0.8, restriction=capi.RESTRICT_INJECT),
     dict(dim=3, n=257, levels=5, dtype=capi.MG_F32, smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW),
+    # red-black with the fused one-pass sweep and the prolongation folded into the first post-sweep
+    dict(dim=3, n=129, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_RBGS, omega=1.0, restriction=capi.RESTRICT_FULLW),
+    dict(dim=3, n=257, levels=5, dtype=capi.MG_F32, smoother=capi.SMOOTH_RBGS, omega=1.0, restriction=capi.RESTRICT_FULLW),
     # anisotropic eps with k ~ log4(1/eps) semi-coarsenings followed by standard ones:
     # eps = 0.01, k = 3 (coarsest 9 x 3 x 3... one-workgroup solve) and eps = 0.25, k = 1 with a coarsest
     # grid too big for one workgroup (33 x 33 x 65: swept with the regular kernels)
@@ -288,6 +291,23 @@ def test_fused_double_sweep_equals_two_sweeps(n, dtype, omega):
         assert np.array_equal(s.get_array(capi.ARR_U, 0), ref2)
         s.smooth(0, capi.SMOOTH_JACOBI, 3, capi.ARR_U, capi.ARR_RHS)      # a pair + a single sweep
         assert np.array_equal(s.get_array(capi.ARR_U, 0), ops.smooth(0, po.SMOOTH_JACOBI, 3, ref2, b))
+
+
+@pytest.mark.parametrize("n,dtype", [(129, capi.MG_F64), (257, capi.MG_F64), (257, capi.MG_F32), (513, capi.MG_F32)])
+def test_fused_red_black_sweep_equals_two_colour_passes(n, dtype):
+    """k_jacobi2<RB>: a whole red-black Gauss-Seidel sweep (red half-sweep on plane p, black half-sweep
+    on plane p-1 in the same pass) against the oracle's in-place colour sweeps, bit for bit."""
+    kw = dict(dim=3, n=n, levels=2, dtype=dtype, length=1.0, alpha=1.0, omega=1.0)
+    s, ops, do = pair(**kw)
+    rng = np.random.default_rng(11)
+    with s:
+        u = rng.random((n, n, n)).astype(s.np); b = rng.random((n, n, n)).astype(s.np)
+        s.set_array(capi.ARR_U, 0, u); s.set_array(capi.ARR_RHS, 0, b)
+        s.smooth(0, capi.SMOOTH_RBGS, 1, capi.ARR_U, capi.ARR_RHS)
+        ref1 = ops.smooth(0, po.SMOOTH_RBGS, 1, u, b)
+        assert np.array_equal(s.get_array(capi.ARR_U, 0), ref1)
+        s.smooth(0, capi.SMOOTH_RBGS, 2, capi.ARR_U, capi.ARR_RHS)
+        assert np.array_equal(s.get_array(capi.ARR_U, 0), ops.smooth(0, po.SMOOTH_RBGS, 2, ref1, b))
 
 
 @pytest.mark.parametrize("dtype", [capi.MG_F64, capi.MG_F32])
