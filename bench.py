@@ -205,7 +205,9 @@ def main():
                      "algorithmic_bytes_per_sweep": bytes_per_sweep},
         "smoother_gbps": achieved,
         # one launch = prolong-add (read u, read coarse, write u: not executed as such) + two sweeps
-        "prolong_folded_pair": ({"kernel": "k_jacobi2<CORR>: J(J(u + P e)) in one pass", "launch_ms": 2 * fu_ms / fu_sweeps,
+        "prolong_folded_pair": ({"kernel": ("k_jacobi2<CORR>: J(J(u + P e)) in one pass" if a.smoother == "jacobi"
+                                            else "post-smoothing segment: RB(u + P e) in one pass, then the remaining sweep(s)"),
+                                 "launch_ms": 2 * fu_ms / fu_sweeps,
                                  "launches_timed": fu_sweeps // 2,
                                  "replaces_bytes": 2 * bytes_per_sweep + int(2.125 * esz * pts_local),
                                  "equivalent_gbps": (2 * bytes_per_sweep + 2.125 * esz * pts_local) / (2 * fu_ms / fu_sweeps * 1e-3) / 1e9}
