@@ -228,13 +228,28 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
         }
         const vec hlo = *(const vec *)(pz + ro_lo);
         const vec hhi = *(const vec *)(pz + ro_hi);
+        // wave-edge scalars and the Dirichlet tail column: loaded here with everything else (inside
+        // the row loop each of them cost its own memory round trip: three per plane and wave)
+        T elv[NR], erv[NR], tlb[CR], tlu[CR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            elv[r] = 0; erv[r] = 0;
+            if (lane == 0) elv[r] = pz[ro[r] - 1];
+            if (lane == 63) erv[r] = pz[ro[r] + V];
+        }
+#pragma unroll
+        for (int j = 0; j < CR; j++) {
+            tlb[j] = 0; tlu[j] = 0;
+            if (tail_lane) {
+                const long long i = zo + (ro[2 * j + 1] - x0c) + gf.nx - 1;
+                tlb[j] = rhs[i]; tlu[j] = u[i];
+            }
+        }
         const bool zb = (z == 0) || (z == gf.nz - 1);
         vec res[NR];
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            T el = 0, er = 0;
-            if (lane == 0) el = pz[ro[r] - 1];
-            if (lane == 63) er = pz[ro[r] + V];
+            const T el = elv[r], er = erv[r];
             const T xm = prev_lane(uc[r][V - 1], el);
             const T xp = next_lane(uc[r][0], er);
             const vec ym = (r == 0) ? hlo : uc[r > 0 ? r - 1 : 0];
@@ -285,10 +300,7 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
             if (centre) {                                // z = 2K (or any plane when z is kept): centre plane
 #pragma unroll
                 for (int m = 0; m < CV; m++) { ywc[j][m] = yw[m]; ctr[j][m] = res[2 * j + 1][2 * m]; }
-                if (tail_lane) {  // odd last fine column (Dirichlet): r = rhs - u on the centre row
-                    const long long i = zo + (ro[2 * j + 1] - x0c) + gf.nx - 1;
-                    ctr_tail[j] = rhs[i] - (T)1 * u[i];
-                }
+                if (tail_lane) ctr_tail[j] = tlb[j] - (T)1 * tlu[j];  // odd last fine column (Dirichlet): r = rhs - u
             }
             if (emitK >= K0 && emitK < K1 && J < gc.ny) {
                 const bool Kbnd = (emitK == 0) || (emitK == gc.nz - 1);
