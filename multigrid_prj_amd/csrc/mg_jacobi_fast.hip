@@ -257,12 +257,20 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
     constexpr int LP = TPR * V + 2 * V;  // LDS row: V pad | TPR*V values | tail column | pad
     typedef typename VecOf<T>::type vec;
     __shared__ __align__(16) T lds[2][TYV][LP];
+    // u values on the wave edges (first / last element of every wave's row segment), published one
+    // plane ahead: the x-neighbour a wave's edge lane needs belongs to the neighbouring wave of the
+    // same workgroup. Loading it from global memory instead cost 2-3 serialised memory round trips
+    // per plane step (the compiler waited after each predicated scalar load): 1.01 -> 0.85 ms per launch.
+    constexpr int NWV = TPR / 64;
+    __shared__ T uedge[2][TYV][NWV][2];
+    __shared__ T utail[2][TYV];  // u(nx-1): the right neighbour of the row's last vector
     const int nblocks = nby * nbz;
     const int per = (nblocks + 7) >> 3;
     const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order
     if (bid >= nblocks) return;                                   // whole workgroup
     const int by = bid % nby, bz = bid / nby;
-    const int t = threadIdx.x, lane = t & 63;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wl = max(wv - 1, 0), wr = min(wv + 1, NWV - 1);  // neighbouring waves (clamped: edge waves ignore the value)
     const int x0 = V * t;                       // the gate guarantees nx - 1 == TPR * V
     const bool tail = (x0 + V == g.nx - 1);     // last thread: also owns the Dirichlet column nx-1
     const bool tailwave = (t >> 6) == (TPR >> 6) - 1;
@@ -365,7 +373,6 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
         }
         return w;
     };
-    auto pe_left = [&](const T (&Yr)[NR]) { return hf * (Yr[CV + 1] + Yr[0]); };  // x0-1 (odd); lane 0 only
     auto pe_right = [&](const T (&Yr)[NR]) { return Yr[CV]; };                     // x0+V (even)
     auto add_vec = [&](vec a, vec w) {
         vec o;
@@ -377,21 +384,43 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
     vec um[TYV], uc[TYV], up[TYV];
     vec vm[TYO], vc[TYO], vp[TYO];  // own-column v(q-1), v(q), v(q+1) of the output rows
     vec bq[TYO];                    // rhs of the output rows on plane q
-    T Yp[6][NR];                    // CORR: y-interpolated correction rows of the current plane p
+    // CORR: halo rows y0-2 / y0+TYO+1 of the current plane p, fetched (and corrected) one step ahead
+    vec hlo = (vec)(0), hhi = (vec)(0);
+    T ter[TYV];                     // tail thread, transient: u(nx-1) on its way to utail
+    auto publish_edges = [&](int slot, const vec (&w)[TYV], const T (&tl)[TYV]) {
+#pragma unroll
+        for (int r = 0; r < TYV; r++) {
+            if (lane == 0) uedge[slot][r][wv][0] = w[r][0];
+            if (lane == 63) uedge[slot][r][wv][1] = w[r][V - 1];
+            if (tail) utail[slot][r] = tl[r];
+        }
+    };
 #pragma unroll
     for (int r = 0; r < TYV; r++) {
         um[r] = *(const vec *)(u + plane_of(z0 - 2) + ro[r]);
         uc[r] = *(const vec *)(u + plane_of(z0 - 1) + ro[r]);
+        ter[r] = 0;
+        if (tail) ter[r] = u[plane_of(z0 - 1) + ro[r] + V];
+    }
+    if (CORR) {
+        hlo = *(const vec *)(u + plane_of(z0 - 1) + ro_lo);
+        hhi = *(const vec *)(u + plane_of(z0 - 1) + ro_hi);
     }
     if (CORR) {
         T Z[4][NR], Y[6][NR];
         zrows(z0 - 2, Z); yrows(Z, Y);
 #pragma unroll
         for (int r = 0; r < TYV; r++) um[r] = add_vec(um[r], pe_vec(Y[1 + r]));
-        zrows(z0 - 1, Z); yrows(Z, Yp);
+        zrows(z0 - 1, Z); yrows(Z, Y);
 #pragma unroll
-        for (int r = 0; r < TYV; r++) uc[r] = add_vec(uc[r], pe_vec(Yp[1 + r]));
+        for (int r = 0; r < TYV; r++) {
+            uc[r] = add_vec(uc[r], pe_vec(Y[1 + r]));
+            ter[r] = ter[r] + pe_right(Y[1 + r]);
+        }
+        hlo = add_vec(hlo, pe_vec(Y[0])); hhi = add_vec(hhi, pe_vec(Y[5]));
     }
+    publish_edges((z0 - 1) & 1, uc, ter);
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < TYO; r++) { vm[r] = (vec)(0); vc[r] = (vec)(0); bq[r] = (vec)(0); }
 
@@ -412,39 +441,50 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
         // ---- every load of this step first ...
         T Ra[4][NR], Rb[4][NR];  // CORR: raw coarse values under plane p+1
         if (CORR) { raw_a(p + 1, Ra); raw_b(p + 1, Rb); }
-        vec hlo = (vec)(0), hhi = (vec)(0);
-        T elv[TYV], erv[TYV];
+        // plane p+1's tail value (and, CORR, halo rows) ride along with `up`: consumed in the next step
+        vec hlo_n = (vec)(0), hhi_n = (vec)(0);
+        if (CORR) {
+            hlo_n = *(const vec *)(u + plane_of(p + 1) + ro_lo);
+            hhi_n = *(const vec *)(u + plane_of(p + 1) + ro_hi);
+        }
+        T ter_n[TYV];
 #pragma unroll
-        for (int r = 0; r < TYV; r++) { elv[r] = 0; erv[r] = 0; }
+        for (int r = 0; r < TYV; r++) {
+            ter_n[r] = 0;
+            if (tail) ter_n[r] = u[plane_of(p + 1) + ro[r] + V];
+        }
         if (pin) {
+            if (!CORR) {
+                hlo = *(const vec *)(pu + ro_lo);
+                hhi = *(const vec *)(pu + ro_hi);
+            }
 #pragma unroll
             for (int r = 0; r < TYV; r++) {
                 if (NTLOAD && r >= 1 && r <= TYO) b[r] = *(const vec *)(rhs + po + ro[r]);
                 else b[r] = *(const vec *)(rhs + po + ro[r]);
-            }
-            hlo = *(const vec *)(pu + ro_lo);
-            hhi = *(const vec *)(pu + ro_hi);
-#pragma unroll
-            for (int r = 0; r < TYV; r++) {
-                if (lane == 0) elv[r] = pu[ro[r] - 1];
-                if (lane == 63) erv[r] = pu[ro[r] + V];
+                if (tail) vtail[r] = rhs[po + ro[r] + V];  // first sweep on the Dirichlet column: v = rhs
             }
         }
         // ---- ... then the arithmetic
-        T Yn[6][NR];  // CORR: correction rows of plane p+1 (become Yp after this step)
         if (CORR) {
-            T Z[4][NR];
+            T Z[4][NR], Yn[6][NR];  // correction rows of plane p+1
             zfin(p + 1, Ra, Rb, Z); yrows(Z, Yn);
 #pragma unroll
-            for (int r = 0; r < TYV; r++) up[r] = add_vec(up[r], pe_vec(Yn[1 + r]));
+            for (int r = 0; r < TYV; r++) {
+                up[r] = add_vec(up[r], pe_vec(Yn[1 + r]));
+                ter_n[r] = ter_n[r] + pe_right(Yn[1 + r]);
+            }
+            hlo_n = add_vec(hlo_n, pe_vec(Yn[0])); hhi_n = add_vec(hhi_n, pe_vec(Yn[5]));
         }
+        publish_edges((p + 1) & 1, up, ter_n);
         if (pin) {
-            if (CORR) { hlo = add_vec(hlo, pe_vec(Yp[0])); hhi = add_vec(hhi, pe_vec(Yp[5])); }
             const bool zbp = (p == 0) || (p == g.nz - 1);
 #pragma unroll
             for (int r = 0; r < TYV; r++) {
-                T el = elv[r], er = erv[r];
-                if (CORR) { el = el + pe_left(Yp[1 + r]); er = er + pe_right(Yp[1 + r]); }
+                // x-neighbours across the wave edges: the neighbouring wave's edge element of plane p
+                // (published in the previous step); the row's last thread has the tail column instead
+                const T el = uedge[p & 1][r][wl][1];
+                const T er = tail ? utail[p & 1][r] : uedge[p & 1][r][wr][0];
                 const T xm = from_prev_lane(uc[r][V - 1], el);
                 const T xp = from_next_lane(uc[r][0], er);
                 const vec ym = (r > 0) ? uc[r > 0 ? r - 1 : 0] : hlo;
@@ -472,7 +512,6 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                     v[r][e] = (rb || (x0 + e == 0)) ? b[r][e] : jac;
                     if (RB && (((x0 + e + y0 - 1 + r + p) & 1) != 0)) v[r][e] = uc[r][e];  // not red: unchanged
                 }
-                if (tail) vtail[r] = rhs[po + ro[r] + V];  // first sweep on the Dirichlet column: v = rhs
             }
         }
 #pragma unroll
@@ -546,12 +585,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
         for (int r = 0; r < TYV; r++) { um[r] = uc[r]; uc[r] = up[r]; }
 #pragma unroll
         for (int r = 0; r < TYO; r++) { vm[r] = vc[r]; vc[r] = vp[r]; bq[r] = b[r + 1]; }
-        if (CORR) {
-#pragma unroll
-            for (int j = 0; j < 6; j++)
-#pragma unroll
-                for (int m = 0; m < NR; m++) Yp[j][m] = Yn[j][m];
-        }
+        if (CORR) { hlo = hlo_n; hhi = hhi_n; }
     }
 }
 
