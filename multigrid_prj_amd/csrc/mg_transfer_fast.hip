@@ -174,14 +174,22 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
     constexpr int V = PV<T>::V, CV = V / 2, NR = 2 * CR + 1;
     typedef typename PV<T>::vec vec;
     __shared__ T edge[2][8][NR];  // [slot][wave][row]: last residual element of each wave
+    // u on the wave edges, published one plane ahead (as in k_jacobi2): the x-neighbour of a wave's
+    // first / last lane is the neighbouring wave's last / first element; only the row's very last
+    // lane needs a value no wave holds (the column after the last vector), fetched one plane ahead
+    __shared__ T ued[2][NR][8][2];
+    __shared__ T utl[2][NR];
     const int nblocks = nby * nbz;
     const int per = (nblocks + 7) >> 3;
     const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order
     if (bid >= nblocks) return;                                   // whole workgroup
     const int J0 = (bid % nby) * CR, bz = bid / nby;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (int)(blockDim.x >> 6);
+    const int wl = max(wv - 1, 0), wr = min(wv + 1, nwv - 1);
+    const bool lastlane = (wv == nwv - 1) && (lane == 63);
     const int ic0 = CV * (wv * 64 + lane);   // first coarse column of the lane
     const int x0 = 2 * ic0;                  // first fine x
+    const int ecol = (x0 + V <= gf.nx - 1) ? V : 0;  // a lane clamped past the row end re-reads its own element (value unused)
     const int x0c = min(x0, gf.pitch - V);   // clamped for loads; every lane stays active
     const bool cin = ic0 + CV - 1 <= gc.nx - 2;      // owns CV real coarse columns (tail column excluded)
     const bool tail_lane = (x0 + V == gf.nx - 1);    // the lane next to the odd last fine column
@@ -207,6 +215,16 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
         um[r] = *(const vec *)(u + (long long)(zs - 1) * gf.plane + ro[r]);  // zs-1 >= -1: ghost plane
         uc[r] = *(const vec *)(u + (long long)zs * gf.plane + ro[r]);
     }
+    {
+        const int sl = zs & 1;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if (lane == 0) ued[sl][r][wv][0] = uc[r][0];
+            if (lane == 63) ued[sl][r][wv][1] = uc[r][V - 1];
+            if (lastlane) utl[sl][r] = u[(long long)zs * gf.plane + ro[r] + ecol];
+        }
+    }
+    __syncthreads();
     T ywm[CR][CV], ywc[CR][CV], ctr[CR][CV], ctr_tail[CR];
 #pragma unroll
     for (int j = 0; j < CR; j++) {
@@ -230,12 +248,13 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
         const vec hhi = *(const vec *)(pz + ro_hi);
         // wave-edge scalars and the Dirichlet tail column: loaded here with everything else (inside
         // the row loop each of them cost its own memory round trip: three per plane and wave)
-        T elv[NR], erv[NR], tlb[CR], tlu[CR];
+        T elv[NR], erv[NR], ern[NR], tlb[CR], tlu[CR];
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            elv[r] = 0; erv[r] = 0;
-            if (lane == 0) elv[r] = pz[ro[r] - 1];
-            if (lane == 63) erv[r] = pz[ro[r] + V];
+            ern[r] = 0;
+            if (lastlane) ern[r] = pz[gf.plane + ro[r] + ecol];  // plane z+1, consumed in the next step
+            elv[r] = ued[z & 1][r][wl][1];
+            erv[r] = (wv == nwv - 1) ? utl[z & 1][r] : ued[z & 1][r][wr][0];
         }
 #pragma unroll
         for (int j = 0; j < CR; j++) {
@@ -272,6 +291,15 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
                 res[r][e] = b[r][e] - sum;
             }
             if (lane == 63) edge[slot][wv][r] = res[r][V - 1];
+        }
+        {
+            const int sl = (z + 1) & 1;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                if (lane == 0) ued[sl][r][wv][0] = up[r][0];
+                if (lane == 63) ued[sl][r][wv][1] = up[r][V - 1];
+                if (lastlane) utl[sl][r] = ern[r];
+            }
         }
         __syncthreads();
         T xw[NR][CV];
