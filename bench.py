@@ -41,8 +41,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", dest="n", type=int, default=513, help="nodes per side (513 = nominal 512^3)")
     ap.add_argument("--levels", type=int, default=6)
     ap.add_argument("--smoother", choices=["jacobi", "rbgs"], default="jacobi")
