@@ -246,7 +246,8 @@ constexpr int J2_TYO = 2, J2_ZC = 16;
 // is the red half-sweep (red points updated from u, black points copied), phase 2 the black
 // half-sweep on the plane behind (black points updated from phase 1's values, red points
 // copied): out = RB(u) in one pass over HBM instead of two (k_sweep3d<OP_RB> twice).
-template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false>
+// ZEROU: u is identically zero (the two pre-smoothing sweeps of a coarse level): nothing is loaded for it.
+template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false, bool ZEROU = false>
 __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
                                                  const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz,
                                                  const T *__restrict__ coarse, Geom gc)
@@ -397,10 +398,10 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
     };
 #pragma unroll
     for (int r = 0; r < TYV; r++) {
-        um[r] = *(const vec *)(u + plane_of(z0 - 2) + ro[r]);
-        uc[r] = *(const vec *)(u + plane_of(z0 - 1) + ro[r]);
+        um[r] = ZEROU ? (vec)(0) : *(const vec *)(u + plane_of(z0 - 2) + ro[r]);
+        uc[r] = ZEROU ? (vec)(0) : *(const vec *)(u + plane_of(z0 - 1) + ro[r]);
         ter[r] = 0;
-        if (tail) ter[r] = u[plane_of(z0 - 1) + ro[r] + V];
+        if (tail && !ZEROU) ter[r] = u[plane_of(z0 - 1) + ro[r] + V];
     }
     if (CORR) {
         hlo = *(const vec *)(u + plane_of(z0 - 1) + ro_lo);
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
         T vtail[TYV];
 #pragma unroll
         for (int r = 0; r < TYV; r++) {
-            up[r] = *(const vec *)(u + plane_of(p + 1) + ro[r]);
+            up[r] = ZEROU ? (vec)(0) : *(const vec *)(u + plane_of(p + 1) + ro[r]);
             b[r] = (vec)(0); v[r] = (vec)(0); vtail[r] = 0;
         }
         // ---- every load of this step first ...
@@ -451,10 +452,10 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
 #pragma unroll
         for (int r = 0; r < TYV; r++) {
             ter_n[r] = 0;
-            if (tail) ter_n[r] = u[plane_of(p + 1) + ro[r] + V];
+            if (tail && !ZEROU) ter_n[r] = u[plane_of(p + 1) + ro[r] + V];
         }
         if (pin) {
-            if (!CORR) {
+            if (!CORR && !ZEROU) {
                 hlo = *(const vec *)(pu + ro_lo);
                 hhi = *(const vec *)(pu + ro_hi);
             }
@@ -679,22 +680,23 @@ bool jacobi2_ok(const Geom &g)
 }
 
 template <typename T>
-void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out)
+void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out, bool zero_u)
 {
     constexpr int V = VecOf<T>::V;
     const int tpr = (g.nx - 1) / V;
     const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = (g.nz + J2_ZC - 1) / J2_ZC;
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
+#define MG_J2K(TPR, D, N, Z) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{})
 #define MG_J2(TPR) \
     do { \
-        if (damped) { if (nt) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
-                      else hipLaunchKernelGGL((k_jacobi2<T, TPR, true, false, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); } \
-        else { if (nt) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
-               else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, false, false>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); } \
+        if (zero_u) { if (damped) MG_J2K(TPR, true, false, true); else MG_J2K(TPR, false, false, true); } \
+        else if (damped) { if (nt) MG_J2K(TPR, true, true, false); else MG_J2K(TPR, true, false, false); } \
+        else { if (nt) MG_J2K(TPR, false, true, false); else MG_J2K(TPR, false, false, false); } \
     } while (0)
     if (tpr == 256) MG_J2(256); else if (tpr == 128) MG_J2(128); else MG_J2(64);
 #undef MG_J2
+#undef MG_J2K
 }
 
 // one red-black Gauss-Seidel sweep (both colours) in one pass: out = RB(u)
@@ -760,8 +762,8 @@ template void launch_jacobi2_corr<double>(hipStream_t, const Geom &, const Geom 
 template void launch_jacobi2_corr<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, float, const float *, const float *, const float *, float *);
 template bool jacobi2_ok<double>(const Geom &);
 template bool jacobi2_ok<float>(const Geom &);
-template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *);
-template void launch_jacobi2<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *);
+template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *, bool);
+template void launch_jacobi2<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *, bool);
 template bool fast_path_ok<double>(const Geom &);
 template bool fast_path_ok<float>(const Geom &);
 template int fast_partials_capacity<double>(const Geom &);

@@ -27,7 +27,8 @@ void launch_jacobi_fast(hipStream_t s, const Geom &g, const Coef<T> &c, T omega,
 // two Jacobi sweeps in one pass (out = J(J(u))), see mg_jacobi_fast.hip
 template <typename T> bool jacobi2_ok(const Geom &g);
 template <typename T>
-void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out);
+void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out,
+                    bool zero_u = false);
 // the same with the V-cycle's prolong-add folded in: out = J(J(u + P coarse)); u is not modified
 template <typename T> bool jacobi2_corr_ok(const Geom &gf, const Geom &gc);
 template <typename T>

@@ -545,13 +545,14 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
     switch (smoother) {
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
-            if (!L.dist && !(x_zero && s == 0) && s + 1 < sweeps && jacobi2_ok<T>(L.g)) {
+            if (!L.dist && s + 1 < sweeps && jacobi2_ok<T>(L.g)) {
                 // two sweeps in one pass over HBM; the pair lands in TMP like a single sweep would
                 if (s == 0 && corr_level >= 0)
                     launch_jacobi2_corr<T>(stream_, L.g, lv_[corr_level].g, c, (T)d_.omega, ptr<T>(ax, level),
                                            ptr<T>(ax, corr_level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level));
-                else
-                    launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level));
+                else  // x_zero: the pair starts from an implicit zero guess (nothing is read for x)
+                    launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
+                                      x_zero && s == 0);
                 std::swap(L.base[ax], L.base[MG_ARR_TMP]);
                 s++;
                 continue;
