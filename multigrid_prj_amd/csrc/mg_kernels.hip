@@ -891,6 +891,116 @@ __global__ __launch_bounds__(SWG) void k_coarse_jacobi_rows(Geom g, Coef<T> c, T
     }
 }
 
+// ---------------------------------------------------------------- LDS coarse solver, lexicographic GS (2-D)
+// Solver::Solve with the Gauss-Seidel smoother (the reference's default, -smt 0) on the coarsest
+// grid: iterate and right-hand side in LDS; the sweep is the anti-diagonal wavefront with one
+// thread per ROW (thread y updates x = d - y at step d: the new left neighbour is its own previous
+// result, the new upper neighbour was stored by thread y-1 one step earlier), so a step is four
+// LDS reads, the update and one barrier among 4 waves instead of 16; the residual norm after the
+// sweep is spread over all 256 threads. Same per-point inputs as the serial loop => same bits.
+constexpr int CGS_THREADS = 256;
+
+template <typename T>
+__global__ __launch_bounds__(CGS_THREADS) void k_coarse_gs_rows2d(Geom g, Coef<T> c, T *x, const T *rhs, int maxit,
+                                                                  double tol, int fixed, CoarseOut *out)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ double part[2][CGS_THREADS / 64];
+    const int nx = g.nx, ny = g.ny, total = nx * ny;
+    T *sx = reinterpret_cast<T *>(smem_raw);
+    T *sb = sx + total;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double sqb = 0.;
+    for (int q = tid; q < total; q += CGS_THREADS) {
+        const int yy = q / nx, xx = q - yy * nx;
+        const long long gi = lidx(g, 0, yy, xx);
+        sx[q] = x[gi];
+        const T b = rhs[gi];
+        sb[q] = b;
+        sqb += (double)b * (double)b;
+    }
+    int parity = 0;
+    auto block_sum = [&](double v) -> double {
+        v = wave_sum_dpp(v);
+        if (lane == 0) part[parity][wv] = v;
+        __syncthreads();
+        double sum = 0;
+#pragma unroll
+        for (int w = 0; w < CGS_THREADS / 64; w++) sum += part[parity][w];
+        parity ^= 1;
+        return sum;
+    };
+    const double nb = block_sum(sqb);
+    auto residual_sumsq = [&]() -> double {
+        double sq = 0.;
+        for (int q = tid; q < total; q += CGS_THREADS) {
+            const int yy = q / nx, xx = q - yy * nx;
+            T sum;
+            if (xx == 0 || xx == nx - 1 || yy == 0 || yy == ny - 1) sum = (T)1 * sx[q];
+            else sum = full_sum<T, 2>(sx, q, nx, 0, c);
+            const T res = sb[q] - sum;
+            sq += (double)res * (double)res;
+        }
+        return block_sum(sq);
+    };
+    const int y = tid;
+    const bool rowin = y < ny, rowb = (y == 0) || (y == ny - 1);
+    auto sweep = [&]() {
+        T mine = 0;  // new x(y, xx-1)
+        for (int d = 0; d <= nx + ny - 2; d++) {
+            const int xx = d - y;
+            if (rowin && xx >= 0 && xx < nx) {
+                const int i = y * nx + xx;
+                T val = sb[i];  // Dirichlet row of the matrix: (b - 0) / 1
+                if (!(rowb || xx == 0 || xx == nx - 1)) {
+                    T sum = 0;
+                    sum += c.cy * sx[i - nx];
+                    sum += c.cx * mine;
+                    sum += c.cx * sx[i + 1];
+                    sum += c.cy * sx[i + nx];
+                    val = div_cd<T>(sb[i] - sum, c);
+                }
+                sx[i] = val;
+                mine = val;
+            }
+            __syncthreads();
+        }
+    };
+    int iters = 0, flag = 0;
+    double nr;
+    if (fixed) {
+        for (int s = 0; s < maxit; s++) sweep();
+        iters = maxit;
+        nr = residual_sumsq();
+    } else {
+        int counter = maxit;
+        nr = residual_sumsq();
+        while (sqrt(nr / nb) > tol) {  // NaN (zero rhs) compares false, like the reference
+            if (counter > 0) {
+                sweep();
+                counter -= 1;
+                iters++;
+                nr = residual_sumsq();
+            } else {
+                flag = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < total; q += CGS_THREADS) {
+        const int yy = q / nx, xx = q - yy * nx;
+        x[lidx(g, 0, yy, xx)] = sx[q];
+    }
+    if (tid == 0) {
+        out->iters = iters;
+        out->flag = flag;
+        out->relres = sqrt(nr / nb);
+        out->sumsq_rhs = nb;
+        out->sumsq_r = nr;
+    }
+}
+
 inline dim3 grid_for(int nx, int ny, int nz)
 {
     return dim3((nx + BX - 1) / BX, (ny + BY - 1) / BY, nz);
@@ -1094,6 +1204,24 @@ static bool try_launch_coarse_jacobi(hipStream_t s, const Geom &g, const Coef<T>
 }
 
 template <typename T>
+static bool try_launch_coarse_gs_rows2d(hipStream_t s, const Geom &g, const Coef<T> &c, T *x, const T *rhs, int maxit,
+                                        double tol, int fixed, CoarseOut *d_out)
+{
+    static const bool enabled = [] { const char *e = getenv("MG_COARSE_GS_ROWS"); return !(e && e[0] == '0'); }();
+    const size_t bytes = 2 * (size_t)g.nx * g.ny * sizeof(T);
+    if (!enabled || g.dim != 2 || g.ny > CGS_THREADS || g.nx < 3 || g.ny < 3 || bytes > (size_t)150 * 1024) return false;
+    auto kern = k_coarse_gs_rows2d<T>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                150 * 1024) != hipSuccess) return false;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(CGS_THREADS), bytes, s, g, c, x, rhs, maxit, tol, fixed, d_out);
+    return true;
+}
+
+template <typename T>
 void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, int smoother,
                          T *x, T *tmp, const T *rhs, int maxit, double tol, int fixed,
                          CoarseOut *d_out)
@@ -1103,6 +1231,7 @@ void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega
         if (g.dim == 3 ? try_launch_coarse_jacobi<T, 3>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out)
                        : try_launch_coarse_jacobi<T, 2>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out)) return;
     }
+    if (smoother == 0 && try_launch_coarse_gs_rows2d<T>(s, g, c, x, rhs, maxit, tol, fixed, d_out)) return;
     if (g.dim == 3) {
         if (try_launch_coarse_lds<T, 3, 5>(s, g, c, omega, smoother, x, rhs, maxit, tol, fixed, d_out)) return;
         hipLaunchKernelGGL((k_coarse_solve<T, 3>), dim3(1), dim3(SWG), 0, s, g, c, omega, smoother, x,
