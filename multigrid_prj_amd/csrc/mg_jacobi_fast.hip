@@ -236,6 +236,20 @@ __global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
 // at 513^3 fp64 (profiles/r01_kbench_fused_double_sweep.log) -- it trades HBM traffic for
 // redundant halo rows and a low occupancy (2 waves/SIMD), hence only ~10 %.
 constexpr int J2_TYO = 2, J2_ZC = 16;
+// z-chunks per launch. Long marches amortise the two extra planes of first-sweep work per chunk,
+// short ones give the smaller levels enough workgroups to fill 256 CUs x 3: 16 planes at 513^3
+// (8481 workgroups; 8 is 5 % slower, 32 equal), 8 at 257^3 (4257; 16 is 6 % slower per cycle).
+static int j2_nbz(const Geom &g)
+{
+    static const int zc_env = [] { const char *e = getenv("MG_J2_ZC"); return e ? atoi(e) : 0; }();
+    int zc = J2_ZC;
+    if (zc_env > 1) zc = zc_env;
+    else {
+        const int nby = (g.ny + J2_TYO - 1) / J2_TYO;
+        while (zc > 4 && nby * ((g.nz + zc - 1) / zc) < 4000) zc >>= 1;
+    }
+    return (g.nz + zc - 1) / zc;
+}
 
 // CORR: every u value read is u + P e_coarse computed on the fly (the V-cycle's prolong-add folded
 // into the post-smoothing pair: the corrected fine array is never written). P e is built with the
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                                                  const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz,
                                                  const T *__restrict__ coarse, Geom gc)
 {
-    constexpr int V = VecOf<T>::V, TYO = J2_TYO, ZC = J2_ZC, TYV = TYO + 2;
+    constexpr int V = VecOf<T>::V, TYO = J2_TYO, TYV = TYO + 2;
     constexpr int CV = V / 2;  // coarse columns owned by this thread
     static_assert(!CORR || TYO == 2, "the correction assumes two output rows (y0 even)");
     constexpr int LP = TPR * V + 2 * V;  // LDS row: V pad | TPR*V values | tail column | pad
@@ -276,6 +290,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
     const bool tail = (x0 + V == g.nx - 1);     // last thread: also owns the Dirichlet column nx-1
     const bool tailwave = (t >> 6) == (TPR >> 6) - 1;
     const int y0 = by * TYO;                    // output rows y0 .. y0+TYO-1; v rows y0-1 .. y0+TYO
+    const int ZC = (g.nz + nbz - 1) / nbz;       // planes marched per workgroup (the launcher picks nbz)
     const int z0 = bz * ZC, z1 = min(z0 + ZC, g.nz);
     long long ro[TYV];
     bool ybnd[TYV];
@@ -684,7 +699,7 @@ void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, con
 {
     constexpr int V = VecOf<T>::V;
     const int tpr = (g.nx - 1) / V;
-    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = (g.nz + J2_ZC - 1) / J2_ZC;
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
 #define MG_J2K(TPR, D, N, Z) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{})
@@ -714,7 +729,7 @@ void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
 {
     constexpr int V = VecOf<T>::V;
     const int tpr = (g.nx - 1) / V;
-    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = (g.nz + J2_ZC - 1) / J2_ZC;
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
 #define MG_RB2(TPR) \
     do { \
@@ -744,7 +759,7 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
 {
     constexpr int V = VecOf<T>::V;
     const int tpr = (g.nx - 1) / V;
-    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = (g.nz + J2_ZC - 1) / J2_ZC;
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool damped = (omega != (T)1);
 #define MG_J2C(TPR) \
