@@ -24,7 +24,10 @@ extern "C" {
 
 enum mg_dtype       { MG_F64 = 0, MG_F32 = 1 };
 /* numbering of the first two mirrors -smt 0 / 1 (include/utilities.hpp:9-14) */
-enum mg_smoother    { MG_SMOOTH_GS_LEX = 0, MG_SMOOTH_JACOBI = 1, MG_SMOOTH_RBGS = 2 };
+/* MG_SMOOTH_ZEBRA_Y (EXTENSION): zebra line Gauss-Seidel, lines along y solved exactly
+ * (Thomas), coloured by the parity of x (+ z): for operators whose y-coupling dominates. The coarsest-grid
+ * solver of such a hierarchy smooths with red-black Gauss-Seidel. */
+enum mg_smoother    { MG_SMOOTH_GS_LEX = 0, MG_SMOOTH_JACOBI = 1, MG_SMOOTH_RBGS = 2, MG_SMOOTH_ZEBRA_Y = 3 };
 enum mg_cycle_kind  { MG_CYCLE_SAWTOOTH = 0,   /* reference cycle, multigrid.hpp:126-145 */
                       MG_CYCLE_V        = 1 }; /* standard V(nu_pre,nu_post), extension  */
 enum mg_restriction { MG_RESTRICT_INJECT = 0,  /* reference: aliasing via mask()         */

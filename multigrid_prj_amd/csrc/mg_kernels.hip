@@ -1001,6 +1001,52 @@ __global__ __launch_bounds__(CGS_THREADS) void k_coarse_gs_rows2d(Geom g, Coef<T
     }
 }
 
+// ---------------------------------------------------------------- zebra line Gauss-Seidel along y
+// One colour pass (EXTENSION). A thread owns one grid line
+// (x, z) of the active colour and solves it with the Thomas algorithm: forward elimination up
+// the line (dp into `dp`, the level's scratch array), back substitution down the line. Lanes are
+// consecutive in x, so every step of the march is a coalesced access; lines run along y, which a
+// z-slab decomposition never cuts. The elimination factors cp(j), den(j) are the same for every
+// line and are tabulated once per level on the host. Same operations in the same order as the
+// CPU restatement => same bits.
+template <typename T, int DIM>
+__global__ __launch_bounds__(256) void k_zebra_y(Geom g, Coef<T> c, int colour, T *__restrict__ u,
+                                                 const T *__restrict__ rhs, T *__restrict__ dp,
+                                                 const T *__restrict__ cp, const T *__restrict__ den)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int z = blockIdx.y * 4 + threadIdx.y;
+    if (x >= g.nx || z >= g.nz) return;
+    const int gz = (DIM == 3) ? g.gz0 + z : 0;
+    if (((x + gz) & 1) != colour) return;
+    const long long base = (long long)z * g.plane + x, sj = g.pitch;
+    const int ny = g.ny;
+    if (x == 0 || x == g.nx - 1 || (DIM == 3 && (gz == 0 || gz == g.gnz - 1))) {
+        for (int j = 0; j < ny; j++) u[base + j * sj] = rhs[base + j * sj];  // identity rows: u = b / 1
+        return;
+    }
+    T dprev = rhs[base];
+    dp[base] = dprev;
+    for (int j = 1; j < ny - 1; j++) {
+        const long long idx = base + j * sj;
+        T S = 0;
+        if (DIM == 3) S += c.cz * u[idx - g.plane];
+        S += c.cx * u[idx - 1];
+        S += c.cx * u[idx + 1];
+        if (DIM == 3) S += c.cz * u[idx + g.plane];
+        dprev = ((rhs[idx] - S) - c.cy * dprev) / den[j];
+        dp[idx] = dprev;
+    }
+    T unext = rhs[base + (ny - 1) * sj];
+    u[base + (ny - 1) * sj] = unext;
+    for (int j = ny - 2; j >= 1; j--) {
+        const long long idx = base + j * sj;
+        unext = dp[idx] - cp[j] * unext;
+        u[idx] = unext;
+    }
+    u[base] = dp[base];
+}
+
 inline dim3 grid_for(int nx, int ny, int nz)
 {
     return dim3((nx + BX - 1) / BX, (ny + BY - 1) / BY, nz);
@@ -1055,6 +1101,25 @@ void launch_gs_lex(hipStream_t s, const Geom &g, const Coef<T> &c, int sweeps, T
         else hipLaunchKernelGGL((k_gs_lex2d_rows<T, 4>), dim3(1), bl, 0, s, g, c, sweeps, u, rhs);
     }
     else hipLaunchKernelGGL((k_gs_lex<T, 2>), dim3(1), dim3(SWG), 0, s, g, c, sweeps, u, rhs);
+}
+
+template <typename T>
+void launch_zebra_y(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u, const T *rhs, T *dp,
+                    const T *cp_den)
+{
+    dim3 bl(64, 4, 1), gr((g.nx + 63) / 64, (g.nz + 3) / 4, 1);
+    if (g.dim == 3) hipLaunchKernelGGL((k_zebra_y<T, 3>), gr, bl, 0, s, g, c, colour, u, rhs, dp, cp_den, cp_den + g.ny);
+    else hipLaunchKernelGGL((k_zebra_y<T, 2>), gr, bl, 0, s, g, c, colour, u, rhs, dp, cp_den, cp_den + g.ny);
+}
+
+// cp(j), den(j) of the line solve, computed in T with the same two operations per row as the CPU restatement; out: 2 * ny values
+template <typename T>
+void zebra_y_factors(const Coef<T> &c, int ny, T *out)
+{
+    T *cp = out, *den = out + ny;
+    cp[0] = 0; den[0] = 1;
+    for (int j = 1; j < ny - 1; j++) { den[j] = c.cd - c.cy * cp[j - 1]; cp[j] = c.cy / den[j]; }
+    cp[ny - 1] = 0; den[ny - 1] = 1;
 }
 
 template <typename T>
@@ -1249,6 +1314,8 @@ void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega
     template void launch_rbgs_colour<T>(hipStream_t, const Geom &, const Coef<T> &, int, T *,      \
                                         const T *);                                                \
     template void launch_gs_lex<T>(hipStream_t, const Geom &, const Coef<T> &, int, T *, const T *); \
+    template void launch_zebra_y<T>(hipStream_t, const Geom &, const Coef<T> &, int, T *, const T *, T *, const T *); \
+    template void zebra_y_factors<T>(const Coef<T> &, int, T *); \
     template void launch_residual<T>(hipStream_t, const Geom &, const Coef<T> &, const T *,        \
                                      const T *, T *, double *, double *);                          \
     template void launch_sumsq<T>(hipStream_t, const Geom &, const T *, double *, double *);       \

@@ -38,7 +38,7 @@ int validate_desc(const mg_desc *d, std::string *why)
     if ((d->n - 1) % step != 0) return fail("n-1 must be a multiple of 2^(levels-1)");
     if ((d->n - 1) / step + 1 < 3) return fail("coarsest grid would have fewer than 3 nodes per side");
     if (d->dtype != MG_F64 && d->dtype != MG_F32) return fail("dtype must be MG_F64 or MG_F32");
-    if (d->smoother < MG_SMOOTH_GS_LEX || d->smoother > MG_SMOOTH_RBGS) return fail("unknown smoother");
+    if (d->smoother < MG_SMOOTH_GS_LEX || d->smoother > MG_SMOOTH_ZEBRA_Y) return fail("unknown smoother");
     if (d->cycle != MG_CYCLE_SAWTOOTH && d->cycle != MG_CYCLE_V) return fail("unknown cycle kind");
     if (d->restriction != MG_RESTRICT_INJECT && d->restriction != MG_RESTRICT_FULLW) return fail("unknown restriction");
     if (d->coarse_mode != MG_COARSE_TOL && d->coarse_mode != MG_COARSE_FIXED) return fail("unknown coarse mode");
@@ -159,6 +159,7 @@ Solver::~Solver()
     for (auto &L : lv_)
         for (auto &b : L.base)
             if (b) (void)hipFree(b);
+    for (auto &L : lv_) if (L.zebra) (void)hipFree(L.zebra);
     for (auto &f : full_) if (f) (void)hipFree(f);
     for (auto &b : stage_base_) if (b) (void)hipFree(b);
     delete comm_;
@@ -262,6 +263,20 @@ int Solver::init()
             MG_HIP(hipMalloc(&L.base[a], nbytes));
             MG_HIP(hipMemsetAsync(L.base[a], 0, nbytes, stream_));
             bytes_ += nbytes;
+        }
+        if (d_.smoother == MG_SMOOTH_ZEBRA_Y) {
+            const size_t nb = 2 * (size_t)L.g.ny * esize();
+            MG_HIP(hipMalloc(&L.zebra, nb));
+            if (d_.dtype == MG_F64) {
+                std::vector<double> f(2 * (size_t)L.g.ny);
+                zebra_y_factors<double>(make_coef<double>(L.coef[0], L.coef[1], L.coef[2], L.coef[3]), L.g.ny, f.data());
+                MG_HIP(hipMemcpy(L.zebra, f.data(), nb, hipMemcpyHostToDevice));
+            } else {
+                std::vector<float> f(2 * (size_t)L.g.ny);
+                zebra_y_factors<float>(make_coef<float>(L.coef[0], L.coef[1], L.coef[2], L.coef[3]), L.g.ny, f.data());
+                MG_HIP(hipMemcpy(L.zebra, f.data(), nb, hipMemcpyHostToDevice));
+            }
+            bytes_ += nb;
         }
         int cap = reduce_partials_capacity(L.g);
         if (cap > max_partials) max_partials = cap;
@@ -595,6 +610,18 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
             launch_rbgs_colour<T>(stream_, L.g, c, 1, ptr<T>(ax, level), ptr<T>(ar, level));
         }
         break;
+    case MG_SMOOTH_ZEBRA_Y:
+        if (sweeps > 0 && !L.zebra) {
+            set_last_error("zebra line smoother: the handle was not created with MG_SMOOTH_ZEBRA_Y");
+            return MG_ERR_BAD_ARG;
+        }
+        for (int s = 0; s < sweeps; s++)
+            for (int colour = 0; colour < 2; colour++) {
+                MG_TRY(exchange(ax, level));  // the other colour's ghost planes (z-slabs; lines run along y)
+                launch_zebra_y<T>(stream_, L.g, c, colour, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
+                                  static_cast<const T *>(L.zebra));
+            }
+        break;
     default:
         if (L.dist && sweeps > 0) {
             set_last_error("lexicographic Gauss-Seidel is sequential across slabs: not available on a distributed level");
@@ -616,7 +643,7 @@ int Solver::smooth(int level, int smoother, int sweeps, int arr_x, int arr_rhs)
 {
     if (!check_arr(arr_x, level, "mg_smooth") || !check_arr(arr_rhs, level, "mg_smooth")) return MG_ERR_BAD_ARG;
     if (arr_x == MG_ARR_TMP || arr_rhs == MG_ARR_TMP || arr_x == arr_rhs || sweeps < 0 ||
-        smoother < MG_SMOOTH_GS_LEX || smoother > MG_SMOOTH_RBGS) {
+        smoother < MG_SMOOTH_GS_LEX || smoother > MG_SMOOTH_ZEBRA_Y) {
         set_last_error("mg_smooth: bad array / smoother / sweeps");
         return MG_ERR_BAD_ARG;
     }
@@ -769,14 +796,16 @@ int Solver::coarse_ex_t(int level, int ax, int ar, int smoother, int maxit, doub
 template <typename T>
 int Solver::coarse_t(int level, int ax, int ar)
 {
-    return coarse_ex_t<T>(level, ax, ar, d_.smoother, d_.coarse_maxit, d_.coarse_tol,
+    // the coarsest-grid solver of a zebra hierarchy smooths with red-black Gauss-Seidel (mg_desc.h)
+    const int sm = d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother;
+    return coarse_ex_t<T>(level, ax, ar, sm, d_.coarse_maxit, d_.coarse_tol,
                           d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0);
 }
 
 int Solver::coarse_solve(int level, int arr_x, int arr_rhs, mg_cycle_stats *st)
 {
-    return coarse_solve_ex(level, arr_x, arr_rhs, d_.smoother, d_.coarse_maxit, d_.coarse_tol,
-                           d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0, st);
+    return coarse_solve_ex(level, arr_x, arr_rhs, d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother,
+                           d_.coarse_maxit, d_.coarse_tol, d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0, st);
 }
 
 int Solver::coarse_solve_ex(int level, int arr_x, int arr_rhs, int smoother, int maxit, double tol, int fixed,
@@ -812,7 +841,8 @@ int Solver::coarse_full_t()
     if (rank_ != 0) return MG_OK;
     Level &L = lv_[T_];
     MG_HIP(hipMemsetAsync(full_[1], 0, (size_t)(gfull_.nz + 2) * (size_t)gfull_.plane * esize(), stream_));
-    launch_coarse_solve<T>(stream_, gfull_, coef_of<T>(L), (T)d_.omega, d_.smoother, fullptr<T>(1), fullptr<T>(2),
+    launch_coarse_solve<T>(stream_, gfull_, coef_of<T>(L), (T)d_.omega,
+                           d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother, fullptr<T>(1), fullptr<T>(2),
                            fullptr<T>(0), d_.coarse_maxit, d_.coarse_tol, d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0,
                            d_coarse_);
     MG_HIP(hipGetLastError());
@@ -827,7 +857,7 @@ int Solver::coarse_level_t(int l, int ax, int ar)
     const long long pts = (long long)L.g.nx * L.g.ny * L.g.gnz;
     const bool big = pts > 32768;  // e.g. the 17 x 17 x 513 coarsest grid of a semi-coarsened hierarchy
     if (big && d_.coarse_mode == MG_COARSE_FIXED) {
-        MG_TRY(smooth_t<T>(l, d_.smoother, d_.coarse_maxit, ax, ar));
+        MG_TRY(smooth_t<T>(l, d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother, d_.coarse_maxit, ax, ar));
         h_fixed_->iters = d_.coarse_maxit; h_fixed_->flag = 0;
         h_fixed_->relres = 0; h_fixed_->sumsq_rhs = 0; h_fixed_->sumsq_r = 0;  // not evaluated on this path
         MG_HIP(hipMemcpyAsync(d_coarse_, h_fixed_, sizeof(CoarseOut), hipMemcpyHostToDevice, stream_));

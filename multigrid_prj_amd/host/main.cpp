@@ -19,7 +19,8 @@ int main(int argc, char **argv)
 
     mg_desc d;
     // -smt 2 ("BiCGSTAB") runs the Jacobi cycle in the reference too (main.cpp:103-106)
-    const int smoother = opt.rbgs ? MG_SMOOTH_RBGS : (opt.smoother == Gauss_Siedel ? MG_SMOOTH_GS_LEX : MG_SMOOTH_JACOBI);
+    const int smoother = opt.zebra ? MG_SMOOTH_ZEBRA_Y
+                                   : opt.rbgs ? MG_SMOOTH_RBGS : (opt.smoother == Gauss_Siedel ? MG_SMOOTH_GS_LEX : MG_SMOOTH_JACOBI);
     mg_desc_reference_defaults(&d, static_cast<int>(opt.N), opt.level, opt.width, opt.alpha, smoother);
     d.dim = opt.dim;
     d.omega = opt.omega;

@@ -28,10 +28,10 @@ struct Options {
     int level = DEFAULT_LEVEL;
     int test = DEFAULT_TEST;
     SMOOTHERS smoother = DEFAULT_METHOD;
-    // extensions (absent from the reference): -dim 3, -cycle v, -omega, -nu1, -nu2, -rbgs,
+    // extensions (absent from the reference): -dim 3, -cycle v, -omega, -nu1, -nu2, -rbgs, -zebra,
     // -fw, -coarse_fixed K, -fp32, -maxit, -eps E (z-coupling multiplier), -semi K (first K coarsenings in x,y only)
     int dim = 2;
-    bool vcycle = false, rbgs = false, full_weighting = false, fp32 = false;
+    bool vcycle = false, rbgs = false, zebra = false, full_weighting = false, fp32 = false;
     double omega = 1.0, eps_z = 1.0;
     int semi = 0;
     int nu1 = 2, nu2 = -1, coarse_fixed = -1, maxit = 1000;

@@ -52,12 +52,14 @@ def _run_ranks(mode, world, case, tmp_path, timeout=600):
     return np.concatenate([p["u"] for p in parts], axis=0), [p["hist"] for p in parts], int(parts[0]["fg"])
 
 
-def _case(tmp_path, n, levels, restriction, cycles=2, semi=0):
+def _case(tmp_path, n, levels, restriction, cycles=2, semi=0, zebra=False):
     desc = dict(dim=3, n=n, levels=levels, dtype=0, length=1.0, alpha=1.0, cycle=1, smoother=1, omega=6 / 7,
                 nu_pre=2, nu_post=2, restriction=restriction, coarse_mode=1, coarse_maxit=20, outer_pre_gs=0,
                 dist_min_n=33)
     if semi:  # eps = 0.25 -> one semi-coarsening (log4(1/eps) = 1), then standard coarsening
         desc.update(semi_xy=1, aniso=(1.0, 1.0, 0.25), omega=0.8, coarse_maxit=80)
+    if zebra:  # strong y-coupling, zebra lines along y (they never cross the z-slabs)
+        desc.update(smoother=3, omega=1.0, aniso=(1.0, 50.0, 1.0))
     b = po.fill_rhs_3d(n, 1.0, 1.0, 1)
     rhs = os.path.join(tmp_path, "rhs.npy")
     np.save(rhs, b)
@@ -128,6 +130,26 @@ def test_hip_distributed_semi_coarsening(world, n, levels, tmp_path):
     for h in hists:
         np.testing.assert_allclose(h, h1, rtol=1e-12)
     assert h1[-1] < 0.5 * h1[-2]  # the mixed hierarchy keeps multigrid convergence (coarse grid only swept)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,levels", [(2, 65, 3), (3, 65, 2)])
+def test_hip_distributed_zebra_line_smoother(world, n, levels, tmp_path):
+    """Zebra lines run along y and the slabs cut z: k ranks equal one rank (and the oracle) bit for bit."""
+    from multigrid_prj_amd import capi
+    case, desc, b = _case(tmp_path, n, levels, 1, zebra=True)
+    u, hists, fg = _run_ranks("hip", world, case, tmp_path)
+    with capi.Solver(capi.make_desc(**desc)) as s:
+        s.set_rhs(b)
+        for _ in range(case["cycles"]):
+            s.cycle()
+        h1, _ = s.solve(0.0, 2)
+        u1 = s.get_solution()
+    assert np.array_equal(u, u1)
+    u_ref, h_ref = _oracle(desc, b, case["cycles"])
+    assert np.array_equal(u, u_ref)
+    # (2 levels: the 33^3 coarse grid only gets 20 red-black sweeps, so it is far from solved)
+    assert h1[-1] < (0.2 if levels >= 3 else 0.7) * h1[-2]
 
 
 @pytest.mark.gpu

@@ -180,6 +180,11 @@ VC = [
     dict(dim=3, n=129, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW),
     dict(dim=3, n=257, levels=5, dtype=capi.MG_F64, smoother=capi.SMOOTH_JACOBI, omega=0.8, restriction=capi.RESTRICT_INJECT),
     dict(dim=3, n=257, levels=5, dtype=capi.MG_F32, smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW),
+    # zebra line smoother along y on an operator whose y-coupling dominates (point smoothers stall at 0.8-0.9)
+    dict(dim=3, n=65, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_ZEBRA_Y, omega=1.0, restriction=capi.RESTRICT_FULLW,
+         aniso=(1.0, 100.0, 1.0)),
+    dict(dim=2, n=129, levels=5, dtype=capi.MG_F64, smoother=capi.SMOOTH_ZEBRA_Y, omega=1.0, restriction=capi.RESTRICT_FULLW,
+         aniso=(1.0, 100.0, 1.0)),
     # red-black with the fused one-pass sweep and the prolongation folded into the first post-sweep
     dict(dim=3, n=129, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_RBGS, omega=1.0, restriction=capi.RESTRICT_FULLW),
     dict(dim=3, n=257, levels=5, dtype=capi.MG_F32, smoother=capi.SMOOTH_RBGS, omega=1.0, restriction=capi.RESTRICT_FULLW),
@@ -329,6 +334,41 @@ def test_fused_red_black_sweep_equals_two_colour_passes(n, dtype):
         assert np.array_equal(s.get_array(capi.ARR_U, 0), ref1)
         s.smooth(0, capi.SMOOTH_RBGS, 2, capi.ARR_U, capi.ARR_RHS)
         assert np.array_equal(s.get_array(capi.ARR_U, 0), ops.smooth(0, po.SMOOTH_RBGS, 2, ref1, b))
+
+
+@pytest.mark.parametrize("case", [
+    dict(dim=2, n=65, dtype=capi.MG_F64, aniso=(1.0, 1.0, 1.0)),
+    dict(dim=3, n=33, dtype=capi.MG_F64, aniso=(1.0, 1.0, 1.0)),
+    dict(dim=3, n=65, dtype=capi.MG_F32, aniso=(1.0, 30.0, 1.0)),
+    dict(dim=3, n=129, dtype=capi.MG_F64, aniso=(1.0, 100.0, 1.0)),
+], ids=lambda c: f"{c['dim']}d-n{c['n']}-t{c['dtype']}")
+def test_zebra_line_smoother_bit_exact(case):
+    """Zebra line Gauss-Seidel along y: each colour pass solves every line of that colour
+    with the Thomas algorithm, one thread per line; same recurrences as the oracle => same bits."""
+    kw = dict(levels=2, length=1.0, alpha=1.0, omega=1.0, smoother=capi.SMOOTH_ZEBRA_Y, **case)
+    s, ops, do = pair(**kw)
+    rng = np.random.default_rng(21)
+    with s:
+        shape = s.level_shape(0)
+        u = rnd(rng, shape, s.np); b = rnd(rng, shape, s.np)
+        s.set_array(capi.ARR_U, 0, u); s.set_array(capi.ARR_RHS, 0, b)
+        s.smooth(0, capi.SMOOTH_ZEBRA_Y, 1, capi.ARR_U, capi.ARR_RHS)
+        ref = ops.smooth(0, po.SMOOTH_ZEBRA_Y, 1, u, b)
+        assert np.array_equal(s.get_array(capi.ARR_U, 0), ref)
+        s.smooth(0, capi.SMOOTH_ZEBRA_Y, 2, capi.ARR_U, capi.ARR_RHS)
+        assert np.array_equal(s.get_array(capi.ARR_U, 0), ops.smooth(0, po.SMOOTH_ZEBRA_Y, 2, ref, b))
+        # level 1 has its own factors
+        sh1 = s.level_shape(1)
+        u1 = rnd(rng, sh1, s.np); b1 = rnd(rng, sh1, s.np)
+        s.set_array(capi.ARR_U, 1, u1); s.set_array(capi.ARR_RHS, 1, b1)
+        s.smooth(1, capi.SMOOTH_ZEBRA_Y, 1, capi.ARR_U, capi.ARR_RHS)
+        assert np.array_equal(s.get_array(capi.ARR_U, 1), ops.smooth(1, po.SMOOTH_ZEBRA_Y, 1, u1, b1))
+
+
+def test_zebra_smoother_needs_a_zebra_handle():
+    with capi.Solver(capi.make_desc(dim=3, n=17, levels=2, smoother=capi.SMOOTH_JACOBI)) as s:
+        with pytest.raises(capi.MgError):
+            s.smooth(0, capi.SMOOTH_ZEBRA_Y, 1, capi.ARR_U, capi.ARR_RHS)
 
 
 @pytest.mark.parametrize("dtype", [capi.MG_F64, capi.MG_F32])

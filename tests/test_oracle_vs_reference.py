@@ -136,3 +136,23 @@ def test_validation_rejects_bad_grids():
     assert po.lib().orc_validate(po.make_desc(n=200, levels=2)) != 0
     assert po.lib().orc_validate(po.make_desc(n=17, levels=5)) != 0
     assert po.lib().orc_validate(po.make_desc(n=17, levels=4)) == 0
+
+
+def test_zebra_line_smoother_handles_a_dominant_y_coupling():
+    """EXTENSION (no reference counterpart, pinned by convergence theory only): with
+    -(dxx + 100 dyy + dzz) the point smoothers leave the y-smooth / x,z-oscillatory error untouched
+    (V-cycle factor 0.8-0.9), zebra line Gauss-Seidel along y restores textbook multigrid."""
+    facs = {}
+    for sm in (po.SMOOTH_RBGS, po.SMOOTH_ZEBRA_Y):
+        kw = dict(dim=3, n=33, levels=4, dtype=po.MG_F64, length=1.0, alpha=1.0, cycle=po.CYCLE_V, nu_pre=2, nu_post=2,
+                  smoother=sm, omega=1.0, restriction=po.RESTRICT_FULLW, coarse_mode=po.COARSE_FIXED, coarse_maxit=30,
+                  outer_pre_gs=0, aniso=(1.0, 100.0, 1.0))
+        s = po.Solver(po.make_desc(**kw)); s.set_rhs(po.fill_rhs_3d(33, 1.0, 1.0, 1))
+        h, _ = s.solve(1e-13, 6)
+        facs[sm] = h[-1] / h[-2]
+    assert facs[po.SMOOTH_RBGS] > 0.6 and facs[po.SMOOTH_ZEBRA_Y] < 0.05
+    # on the isotropic operator it is simply a stronger smoother than red-black
+    kw.update(aniso=(1.0, 1.0, 1.0), smoother=po.SMOOTH_ZEBRA_Y)
+    s = po.Solver(po.make_desc(**kw)); s.set_rhs(po.fill_rhs_3d(33, 1.0, 1.0, 1))
+    h, _ = s.solve(1e-13, 6)
+    assert h[-1] / h[-2] < 0.1
