@@ -262,7 +262,7 @@ static int j2_nbz(const Geom &g)
 // copied): out = RB(u) in one pass over HBM instead of two (k_sweep3d<OP_RB> twice).
 // ZEROU: u is identically zero (the two pre-smoothing sweeps of a coarse level): nothing is loaded for it.
 template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false, bool ZEROU = false>
-__global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
+__global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
                                                  const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz,
                                                  const T *__restrict__ coarse, Geom gc)
 {
@@ -284,7 +284,8 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
     const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order
     if (bid >= nblocks) return;                                   // whole workgroup
     const int by = bid % nby, bz = bid / nby;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);    // wave index: scalar
     const int wl = max(wv - 1, 0), wr = min(wv + 1, NWV - 1);  // neighbouring waves (clamped: edge waves ignore the value)
     const int x0 = V * t;                       // the gate guarantees nx - 1 == TPR * V
     const bool tail = (x0 + V == g.nx - 1);     // last thread: also owns the Dirichlet column nx-1
@@ -292,16 +293,18 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
     const int y0 = by * TYO;                    // output rows y0 .. y0+TYO-1; v rows y0-1 .. y0+TYO
     const int ZC = (g.nz + nbz - 1) / nbz;       // planes marched per workgroup (the launcher picks nbz)
     const int z0 = bz * ZC, z1 = min(z0 + ZC, g.nz);
-    long long ro[TYV];
+    // row offsets are workgroup-uniform (SGPRs); the lane's x0 is added last so that the loads can
+    // use the scalar-base + 32-bit-offset addressing form instead of a 64-bit VGPR pair per address
+    long long urow[TYV];
     bool ybnd[TYV];
 #pragma unroll
     for (int r = 0; r < TYV; r++) {
         const int y = min(max(y0 - 1 + r, 0), g.ny - 1);
         ybnd[r] = (y == 0) || (y == g.ny - 1);
-        ro[r] = (long long)y * g.pitch + x0;
+        urow[r] = (long long)y * g.pitch;
     }
-    const long long ro_lo = (long long)min(max(y0 - 2, 0), g.ny - 1) * g.pitch + x0;
-    const long long ro_hi = (long long)min(y0 + TYO + 1, g.ny - 1) * g.pitch + x0;
+    const long long urow_lo = (long long)min(max(y0 - 2, 0), g.ny - 1) * g.pitch;
+    const long long urow_hi = (long long)min(y0 + TYO + 1, g.ny - 1) * g.pitch;
     auto plane_of = [&](int p) { return (long long)min(max(p, -1), g.nz) * g.plane; };  // stay inside the allocation
 
     // ---- on-the-fly prolongation (CORR) ------------------------------------------------------
@@ -312,23 +315,24 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
     constexpr int NR = CV + 2;
     const T hf = (T)0.5;
     typedef T cvec __attribute__((ext_vector_type(CV > 1 ? CV : 2)));
-    int crow[4];   // offsets of coarse rows yc0-1 .. yc0+2 (clamped into the grid) + own first column
-    int ecol = 0;  // edge lanes: column offset relative to the own first column
+    int ucrow[4];          // offsets of coarse rows yc0-1 .. yc0+2 (clamped into the grid): workgroup-uniform
+    const int ic0 = CV * t;   // own first coarse column
+    const int ice = ic0 + ((lane == 63) ? CV : 0);  // lane 63: the column past the wave (ic0 elsewhere: value unused)
     if (CORR) {
-        const int yc0 = y0 >> 1, ic0 = CV * t;
+        const int yc0 = y0 >> 1;
 #pragma unroll
-        for (int j = 0; j < 4; j++) crow[j] = min(max(yc0 - 1 + j, 0), gc.ny - 1) * gc.pitch + ic0;
-        ecol = (lane == 0) ? (ic0 > 0 ? -1 : 0) : (lane == 63 ? CV : 0);
+        for (int j = 0; j < 4; j++) ucrow[j] = min(max(yc0 - 1 + j, 0), gc.ny - 1) * gc.pitch;
     }
     auto load_crow = [&](const T *base, int j, T (&d)[NR]) {
-        if (CV == 1) d[0] = base[crow[j]];
+        const T *row = base + ucrow[j];
+        if (CV == 1) d[0] = row[ic0];
         else {
-            const cvec w = *(const cvec *)(base + crow[j]);
+            const cvec w = *(const cvec *)(row + ic0);
 #pragma unroll
             for (int m = 0; m < CV; m++) d[m] = w[m];
         }
         d[CV] = 0;
-        d[CV + 1] = base[crow[j] + ecol];  // only the edge lanes' value is consumed (ecol = 0 elsewhere)
+        d[CV + 1] = row[ice];
     };
     // Loads and arithmetic are kept apart so that a plane step issues ALL its loads (u, rhs,
     // coarse) before the first wait: raw_a/raw_b only load, zfin only computes.
@@ -413,14 +417,14 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
     };
 #pragma unroll
     for (int r = 0; r < TYV; r++) {
-        um[r] = ZEROU ? (vec)(0) : *(const vec *)(u + plane_of(z0 - 2) + ro[r]);
-        uc[r] = ZEROU ? (vec)(0) : *(const vec *)(u + plane_of(z0 - 1) + ro[r]);
+        um[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (plane_of(z0 - 2) + urow[r])) + x0);
+        uc[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (plane_of(z0 - 1) + urow[r])) + x0);
         ter[r] = 0;
-        if (tail && !ZEROU) ter[r] = u[plane_of(z0 - 1) + ro[r] + V];
+        if (tail && !ZEROU) ter[r] = (u + (plane_of(z0 - 1) + urow[r]))[x0 + V];
     }
     if (CORR) {
-        hlo = *(const vec *)(u + plane_of(z0 - 1) + ro_lo);
-        hhi = *(const vec *)(u + plane_of(z0 - 1) + ro_hi);
+        hlo = *(const vec *)((u + (plane_of(z0 - 1) + urow_lo)) + x0);
+        hhi = *(const vec *)((u + (plane_of(z0 - 1) + urow_hi)) + x0);
     }
     if (CORR) {
         T Z[4][NR], Y[6][NR];
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
         T vtail[TYV];
 #pragma unroll
         for (int r = 0; r < TYV; r++) {
-            up[r] = ZEROU ? (vec)(0) : *(const vec *)(u + plane_of(p + 1) + ro[r]);
+            up[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (plane_of(p + 1) + urow[r])) + x0);
             b[r] = (vec)(0); v[r] = (vec)(0); vtail[r] = 0;
         }
         // ---- every load of this step first ...
@@ -460,25 +464,25 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
         // plane p+1's tail value (and, CORR, halo rows) ride along with `up`: consumed in the next step
         vec hlo_n = (vec)(0), hhi_n = (vec)(0);
         if (CORR) {
-            hlo_n = *(const vec *)(u + plane_of(p + 1) + ro_lo);
-            hhi_n = *(const vec *)(u + plane_of(p + 1) + ro_hi);
+            hlo_n = *(const vec *)((u + (plane_of(p + 1) + urow_lo)) + x0);
+            hhi_n = *(const vec *)((u + (plane_of(p + 1) + urow_hi)) + x0);
         }
         T ter_n[TYV];
 #pragma unroll
         for (int r = 0; r < TYV; r++) {
             ter_n[r] = 0;
-            if (tail && !ZEROU) ter_n[r] = u[plane_of(p + 1) + ro[r] + V];
+            if (tail && !ZEROU) ter_n[r] = (u + (plane_of(p + 1) + urow[r]))[x0 + V];
         }
         if (pin) {
             if (!CORR && !ZEROU) {
-                hlo = *(const vec *)(pu + ro_lo);
-                hhi = *(const vec *)(pu + ro_hi);
+                hlo = *(const vec *)((pu + urow_lo) + x0);
+                hhi = *(const vec *)((pu + urow_hi) + x0);
             }
 #pragma unroll
             for (int r = 0; r < TYV; r++) {
-                if (NTLOAD && r >= 1 && r <= TYO) b[r] = *(const vec *)(rhs + po + ro[r]);
-                else b[r] = *(const vec *)(rhs + po + ro[r]);
-                if (tail) vtail[r] = rhs[po + ro[r] + V];  // first sweep on the Dirichlet column: v = rhs
+                if (NTLOAD && r >= 1 && r <= TYO) b[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
+                else b[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
+                if (tail) vtail[r] = (rhs + (po + urow[r]))[x0 + V];  // first sweep on the Dirichlet column: v = rhs
             }
         }
         // ---- ... then the arithmetic
@@ -528,6 +532,10 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                     v[r][e] = (rb || (x0 + e == 0)) ? b[r][e] : jac;
                     if (RB && (((x0 + e + y0 - 1 + r + p) & 1) != 0)) v[r][e] = uc[r][e];  // not red: unchanged
                 }
+                // v(p) goes to its LDS slot at once (the slot held v(p-2), last read before the previous
+                // barrier): the registers of v rows 0 and TYV-1 and of vtail are free for the second sweep
+                *(vec *)&lds[p & 1][r][V + x0] = v[r];
+                if (tail) lds[p & 1][r][V + x0 + V] = vtail[r];
             }
         }
 #pragma unroll
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                         res[e] = (rb || (x0 + e == 0)) ? bq[r][e] : jac;
                         if (RB && (((x0 + e + y + q) & 1) == 0)) res[e] = vc[r][e];  // not black: unchanged
                     }
-                    __builtin_nontemporal_store(res, (vec *)(out + qo + ro[lr]));
+                    __builtin_nontemporal_store(res, (vec *)((out + (qo + urow[lr])) + x0));
                     if (tailwave && lane >= 56) {
                         // column nx-1 (Dirichlet) as one full 128-byte line: value + zero padding
                         const int j = lane - 56;
@@ -578,7 +586,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                         const int xs = g.nx - 1 + V * j;
                         const int line_end = ((g.nx - 1) / LINE + 1) * LINE;
                         if (xs < line_end) {
-                            const long long rb0 = qo + (ro[lr] - x0);
+                            const long long rb0 = qo + urow[lr];
                             vec tv = (vec)(0);
                             if (j == 0) tv[0] = rhs[rb0 + g.nx - 1];
                             __builtin_nontemporal_store(tv, (vec *)(out + rb0 + xs));
@@ -587,8 +595,7 @@ __global__ __launch_bounds__(TPR) void k_jacobi2(Geom g, Coef<T> c, T omega, con
                 }
             }
         }
-        // ---- publish v(p) for the next plane's x/y neighbours
-        {
+        if (!pin) {  // planes outside the grid: their slot must still hold the zeros the second sweep reads
             const int sl = p & 1;
 #pragma unroll
             for (int r = 0; r < TYV; r++) {
