@@ -308,31 +308,24 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
     auto plane_of = [&](int p) { return (long long)min(max(p, -1), g.nz) * g.plane; };  // stay inside the allocation
 
     // ---- on-the-fly prolongation (CORR) ------------------------------------------------------
-    // Per coarse row the thread loads its own CV columns (one coalesced 8-byte load); the column to
-    // the right comes from the next lane by DPP; the wave's edge lanes load the one column a
-    // neighbouring wave owns (lane 0: left, for u(x0-1); lane 63: right), merged into one load.
-    // A correction "row" is NR values: [0..CV) own columns, [CV] right column, [CV+1] edge column.
-    constexpr int NR = CV + 2;
+    // Per coarse row the thread loads its own CV columns AND the column to their right with one
+    // 16-byte load at 8-byte alignment (neighbouring lanes overlap by one column): no exchange between
+    // lanes or waves is needed. A correction "row" is NR values: [0..CV) own columns, [CV] right column.
+    // (The row's last thread reads up to gc.nx - 1 in fp64, one element of row padding beyond it in fp32.)
+    constexpr int NR = CV + 1;
     const T hf = (T)0.5;
-    typedef T cvec __attribute__((ext_vector_type(CV > 1 ? CV : 2)));
+    typedef T cwide __attribute__((ext_vector_type(16 / sizeof(T)), aligned(8)));
     int ucrow[4];          // offsets of coarse rows yc0-1 .. yc0+2 (clamped into the grid): workgroup-uniform
     const int ic0 = CV * t;   // own first coarse column
-    const int ice = ic0 + ((lane == 63) ? CV : 0);  // lane 63: the column past the wave (ic0 elsewhere: value unused)
     if (CORR) {
         const int yc0 = y0 >> 1;
 #pragma unroll
         for (int j = 0; j < 4; j++) ucrow[j] = min(max(yc0 - 1 + j, 0), gc.ny - 1) * gc.pitch;
     }
     auto load_crow = [&](const T *base, int j, T (&d)[NR]) {
-        const T *row = base + ucrow[j];
-        if (CV == 1) d[0] = row[ic0];
-        else {
-            const cvec w = *(const cvec *)(row + ic0);
+        const cwide w = *(const cwide *)((base + ucrow[j]) + ic0);
 #pragma unroll
-            for (int m = 0; m < CV; m++) d[m] = w[m];
-        }
-        d[CV] = 0;
-        d[CV + 1] = row[ice];
+        for (int m = 0; m < NR; m++) d[m] = w[m];
     };
     // Loads and arithmetic are kept apart so that a plane step issues ALL its loads (u, rhs,
     // coarse) before the first wait: raw_a/raw_b only load, zfin only computes.
@@ -364,7 +357,6 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
                 const T z = odd ? hf * (Ra[j][m] + Rb[j][m]) : Ra[j][m];
                 Z[j][m] = in ? z : (T)0;
             }
-            Z[j][CV] = from_next_lane(Z[j][0], Z[j][CV + 1]);
         }
     };
     auto zrows = [&](int P, T (&Z)[4][NR]) {
