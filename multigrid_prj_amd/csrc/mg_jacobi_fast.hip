@@ -16,8 +16,9 @@
 //  * the odd last column (n = 2^k+1) is written as ONE full 128-byte line (boundary value
 //    + the row's zero padding): an 8-byte partial-line store per row costs ~5 % of the
 //    sweep on HBM3E;
-//  * arithmetic order, -ffp-contract=off and IEEE division are those of mg_kernels.hip:
-//    results are bit-identical to the generic kernels and to the oracle.
+//  * arithmetic order, -ffp-contract=off and the correctly rounded division (mg_geom.h: div_cd_n)
+//    are those of mg_kernels.hip: results are bit-identical to the generic kernels and to the
+//    CPU restatement the tests compare with.
 // MFMA is not used: there is no contraction here, the kernel is HBM-bound (24 B/point).
 #include "mg_kernels.h"
 
@@ -231,10 +232,10 @@ __global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
 // (overlapped tiling in y) from u planes p-1, p, p+1 held in registers; (2) the second sweep on
 // plane q = p-1 of the TYO output rows: its z-neighbours v(q-1), v(q+1) are the thread's own
 // registers, its x/y-neighbours come from the LDS copy of v(q) published one step earlier;
-// (3) v(p) is published to the other LDS slot; one barrier per plane. Same per-point
-// arithmetic as two k_sweep3d launches => bit-identical; measured 1.10 ms vs 1.23 ms per pair
-// at 513^3 fp64 (profiles/r01_kbench_fused_double_sweep.log) -- it trades HBM traffic for
-// redundant halo rows and a low occupancy (2 waves/SIMD), hence only ~10 %.
+// (3) v(p) goes to the other LDS slot; one barrier per plane. The x-neighbours across wave
+// boundaries travel through a small LDS mailbox one plane ahead (uedge / utail). Same per-point
+// arithmetic as two k_sweep3d launches => bit-identical; 0.85 ms against 2 x 0.60 ms per pair at
+// 513^3 fp64 (3 workgroups per CU; DESIGN.md section 4 has the history).
 constexpr int J2_TYO = 2, J2_ZC = 16;
 // z-chunks per launch. Long marches amortise the two extra planes of first-sweep work per chunk,
 // short ones give the smaller levels enough workgroups to fill 256 CUs x 3: 16 planes at 513^3
@@ -254,7 +255,7 @@ static int j2_nbz(const Geom &g)
 // CORR: every u value read is u + P e_coarse computed on the fly (the V-cycle's prolong-add folded
 // into the post-smoothing pair: the corrected fine array is never written). P e is built with the
 // prolongation's own expression tree -- z midpoints, then y, then x, each 0.5*(a+b) -- from the
-// coarse values of 4 coarse rows per plane (own columns + DPP neighbours, L1/L2-hot), so
+// coarse values of 4 coarse rows per plane (own and right column in one 16-byte load, L1/L2-hot), so
 // u + P e has exactly the bits k_prolong3d_fast<ADD> would have stored.
 // RB: the same pipeline runs ONE red-black Gauss-Seidel sweep instead of two Jacobi sweeps: phase 1
 // is the red half-sweep (red points updated from u, black points copied), phase 2 the black
