@@ -265,7 +265,7 @@ static int j2_nbz(const Geom &g)
 template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false, bool ZEROU = false>
 __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
                                                  const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz,
-                                                 const T *__restrict__ coarse, Geom gc)
+                                                 const T *__restrict__ coarse, Geom gc, int zhalo)
 {
     constexpr int V = VecOf<T>::V, TYO = J2_TYO, TYV = TYO + 2;
     constexpr int CV = V / 2;  // coarse columns owned by this thread
@@ -306,7 +306,9 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
     }
     const long long urow_lo = (long long)min(max(y0 - 2, 0), g.ny - 1) * g.pitch;
     const long long urow_hi = (long long)min(y0 + TYO + 1, g.ny - 1) * g.pitch;
-    auto plane_of = [&](int p) { return (long long)min(max(p, -1), g.nz) * g.plane; };  // stay inside the allocation
+    // zhalo = planes that exist below local plane 0 / above plane nz-1: 1 for a whole level (the ghost
+    // planes), 2 when g describes the inner planes 1 .. nz-2 of a z-slab (launch_jacobi2_slab)
+    auto plane_of = [&](int p) { return (long long)min(max(p, -zhalo), g.nz - 1 + zhalo) * g.plane; };
 
     // ---- on-the-fly prolongation (CORR) ------------------------------------------------------
     // Per coarse row the thread loads its own CV columns AND the column to their right with one
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
         // planes outside the grid (p = -1 or nz, first / last chunk only) are never evaluated: their
         // v only feeds Dirichlet outputs, and the wave-edge load of row 0 on plane -1 would fall
         // in front of the allocation
-        const bool pin = (p >= 0) && (p < g.nz);
+        const bool pin = (g.gz0 + p >= 0) && (g.gz0 + p < g.gnz);  // a plane of the global grid
         vec b[TYV], v[TYV];
         T vtail[TYV];
 #pragma unroll
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
         }
         publish_edges((p + 1) & 1, up, ter_n);
         if (pin) {
-            const bool zbp = (p == 0) || (p == g.nz - 1);
+            const bool zbp = (g.gz0 + p == 0) || (g.gz0 + p == g.gnz - 1);
 #pragma unroll
             for (int r = 0; r < TYV; r++) {
                 // x-neighbours across the wave edges: the neighbouring wave's edge element of plane p
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
                     T jac = quo[e];
                     if (DAMPED) jac = uc[r][e] + omega * (jac - uc[r][e]);
                     v[r][e] = (rb || (x0 + e == 0)) ? b[r][e] : jac;
-                    if (RB && (((x0 + e + y0 - 1 + r + p) & 1) != 0)) v[r][e] = uc[r][e];  // not red: unchanged
+                    if (RB && (((x0 + e + y0 - 1 + r + g.gz0 + p) & 1) != 0)) v[r][e] = uc[r][e];  // not red: unchanged
                 }
                 // v(p) goes to its LDS slot at once (the slot held v(p-2), last read before the previous
                 // barrier): the registers of v rows 0 and TYV-1 and of vtail are free for the second sweep
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
         // ---- second sweep on plane q = p-1
         const int q = p - 1;
         if (q >= z0 && q < z1) {
-            const bool zbq = (q == 0) || (q == g.nz - 1);
+            const bool zbq = (g.gz0 + q == 0) || (g.gz0 + q == g.gnz - 1);
             const int sl = q & 1;
             const long long qo = (long long)q * g.plane;
 #pragma unroll
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
                         T jac = quo[e];
                         if (DAMPED) jac = vc[r][e] + omega * (jac - vc[r][e]);
                         res[e] = (rb || (x0 + e == 0)) ? bq[r][e] : jac;
-                        if (RB && (((x0 + e + y + q) & 1) == 0)) res[e] = vc[r][e];  // not black: unchanged
+                        if (RB && (((x0 + e + y + g.gz0 + q) & 1) == 0)) res[e] = vc[r][e];  // not black: unchanged
                     }
                     __builtin_nontemporal_store(res, (vec *)((out + (qo + urow[lr])) + x0));
                     if (tailwave && lane >= 56) {
@@ -694,15 +696,30 @@ bool jacobi2_ok(const Geom &g)
     return (g.nx - 1) % V == 0 && (v == 64 || v == 128 || v == 256);
 }
 
+// the same kernel on the inner planes of a z-slab (mg_solver.cpp: pair_on_slab_t): `g` = the slab's geometry
 template <typename T>
-void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out, bool zero_u)
+bool jacobi2_slab_ok(const Geom &g)
+{
+    constexpr int V = VecOf<T>::V;
+    static const bool enabled = [] {
+        const char *e = getenv("MG_FUSED_PAIR"), *f = getenv("MG_FUSED_SLAB");
+        return !(e && e[0] == '0') && !(f && f[0] == '0');
+    }();
+    if (!enabled || g.dim != 3 || g.ny < 3 || g.nz < 6) return false;
+    const int v = (g.nx - 1) / V;
+    return (g.nx - 1) % V == 0 && (v == 64 || v == 128 || v == 256);
+}
+
+template <typename T>
+void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out, bool zero_u,
+                    int zhalo)
 {
     constexpr int V = VecOf<T>::V;
     const int tpr = (g.nx - 1) / V;
     const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
-#define MG_J2K(TPR, D, N, Z) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{})
+#define MG_J2K(TPR, D, N, Z) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}, zhalo)
 #define MG_J2(TPR) \
     do { \
         if (zero_u) { if (damped) MG_J2K(TPR, true, false, true); else MG_J2K(TPR, false, false, true); } \
@@ -733,8 +750,8 @@ void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
 #define MG_RB2(TPR) \
     do { \
-        if (coarse) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, coarse, gc); \
-        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
+        if (coarse) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, coarse, gc, 1); \
+        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}, 1); \
     } while (0)
     if (tpr == 256) MG_RB2(256); else if (tpr == 128) MG_RB2(128); else MG_RB2(64);
 #undef MG_RB2
@@ -764,8 +781,8 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
     const bool damped = (omega != (T)1);
 #define MG_J2C(TPR) \
     do { \
-        if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
-        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
+        if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 1); \
+        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 1); \
     } while (0)
     if (tpr == 256) MG_J2C(256); else if (tpr == 128) MG_J2C(128); else MG_J2C(64);
 #undef MG_J2C
@@ -777,8 +794,10 @@ template void launch_jacobi2_corr<double>(hipStream_t, const Geom &, const Geom 
 template void launch_jacobi2_corr<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, float, const float *, const float *, const float *, float *);
 template bool jacobi2_ok<double>(const Geom &);
 template bool jacobi2_ok<float>(const Geom &);
-template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *, bool);
-template void launch_jacobi2<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *, bool);
+template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *, bool, int);
+template bool jacobi2_slab_ok<double>(const Geom &);
+template bool jacobi2_slab_ok<float>(const Geom &);
+template void launch_jacobi2<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *, bool, int);
 template bool fast_path_ok<double>(const Geom &);
 template bool fast_path_ok<float>(const Geom &);
 template int fast_partials_capacity<double>(const Geom &);

@@ -541,6 +541,44 @@ bool Solver::can_fold_prolong(int level) const
            jacobi2_corr_ok<T>(lv_[level].g, lv_[level + 1].g);
 }
 
+// Two Jacobi sweeps of U on a z-slab with the fused kernel (depth-1 ghost planes are enough):
+//   a. halo of u;
+//   b. sweep 1 on the two outermost planes of either end -> v in the level's E array (free in a
+//      V-cycle), and the halo of v starts moving on the communication stream;
+//   c. meanwhile the fused pair computes the output planes 1 .. nz-2 (its internal first sweep needs
+//      u on planes -1 .. nz, i.e. only the ghosts of step a);
+//   d. sweep 2 on planes 0 and nz-1 from v once its ghosts are in.
+// Same arithmetic per point as two exchanged single sweeps => same bits as one GPU.
+template <typename T>
+int Solver::pair_on_slab_t(int level)
+{
+    Level &L = lv_[level];
+    const Geom &g = L.g;
+    Coef<T> c = coef_of<T>(L);
+    const T om = (T)d_.omega;
+    T *px = ptr<T>(MG_ARR_U, level), *pr = ptr<T>(MG_ARR_RHS, level), *pt = ptr<T>(MG_ARR_TMP, level),
+      *pv = ptr<T>(MG_ARR_E, level);
+    const long long pl = g.plane;
+    MG_TRY(exchange(MG_ARR_U, level));
+    Geom glo = g; glo.nz = 2;
+    launch_jacobi<T>(stream_, glo, c, om, px, pr, pv, false);
+    Geom ghi = g; ghi.nz = 2; ghi.gz0 = g.gz0 + g.nz - 2;
+    const long long ohi = (long long)(g.nz - 2) * pl;
+    launch_jacobi<T>(stream_, ghi, c, om, px + ohi, pr + ohi, pv + ohi, false);
+    MG_TRY(exchange_begin(MG_ARR_E, level));
+    Geom gb = g; gb.nz = g.nz - 2; gb.gz0 = g.gz0 + 1;
+    launch_jacobi2<T>(stream_, gb, c, om, px + pl, pr + pl, pt + pl, false, 2);
+    MG_TRY(exchange_end());
+    Geom g0 = g; g0.nz = 1;
+    launch_jacobi<T>(stream_, g0, c, om, pv, pr, pt, false);
+    Geom g1 = g; g1.nz = 1; g1.gz0 = g.gz0 + g.nz - 1;
+    const long long o1 = (long long)(g.nz - 1) * pl;
+    launch_jacobi<T>(stream_, g1, c, om, pv + o1, pr + o1, pt + o1, false);
+    MG_HIP(hipGetLastError());
+    std::swap(L.base[MG_ARR_U], L.base[MG_ARR_TMP]);
+    return MG_OK;
+}
+
 // corr_level >= 0: x is still missing the coarse-grid correction P u_{corr_level}; the first fused
 // pair applies it on the fly (caller checked can_fold_prolong)
 template <typename T>
@@ -560,6 +598,12 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
     switch (smoother) {
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
+            if (L.dist && overlap_ && d_.cycle == MG_CYCLE_V && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps &&
+                !(x_zero && s == 0) && jacobi2_slab_ok<T>(L.g)) {  // E is free in a V-cycle: scratch for the boundary planes' first sweep
+                MG_TRY(pair_on_slab_t<T>(level));
+                s++;
+                continue;
+            }
             if (!L.dist && s + 1 < sweeps && jacobi2_ok<T>(L.g)) {
                 // two sweeps in one pass over HBM; the pair lands in TMP like a single sweep would
                 if (s == 0 && corr_level >= 0)

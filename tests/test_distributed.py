@@ -91,7 +91,7 @@ def test_slab_decomposition_model_gloo(world, n, levels, restriction, expect_fg,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,levels,restriction", [(2, 65, 3, 1), (2, 65, 4, 0), (3, 129, 3, 1), (2, 129, 4, 1)])
+@pytest.mark.parametrize("world,n,levels,restriction", [(2, 65, 3, 1), (2, 65, 4, 0), (3, 129, 3, 1), (2, 129, 4, 1), (2, 257, 4, 1)])
 def test_hip_distributed_solver_two_processes_one_gpu(world, n, levels, restriction, tmp_path):
     from multigrid_prj_amd import capi
     case, desc, b = _case(tmp_path, n, levels, restriction)
