@@ -265,7 +265,7 @@ static int j2_nbz(const Geom &g)
 template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false, bool ZEROU = false>
 __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
                                                  const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz,
-                                                 const T *__restrict__ coarse, Geom gc, int zhalo)
+                                                 const T *__restrict__ coarse, Geom gc)
 {
     constexpr int V = VecOf<T>::V, TYO = J2_TYO, TYV = TYO + 2;
     constexpr int CV = V / 2;  // coarse columns owned by this thread
@@ -307,7 +307,11 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
     const long long urow_lo = (long long)min(max(y0 - 2, 0), g.ny - 1) * g.pitch;
     const long long urow_hi = (long long)min(y0 + TYO + 1, g.ny - 1) * g.pitch;
     // zhalo = planes that exist below local plane 0 / above plane nz-1: 1 for a whole level (the ghost
-    // planes), 2 when g describes the inner planes 1 .. nz-2 of a z-slab (launch_jacobi2_slab)
+    // planes), 2 when g describes the inner planes 1 .. nz-2 of a z-slab (pair_on_slab_t: the only
+    // launches whose g is not the whole grid in z)
+    const int zhalo = (!CORR && g.gnz != g.nz) ? 2 : 1;
+    // global z of local plane 0 and global plane count (the folding variant only runs on whole levels)
+    const int gzo = CORR ? 0 : g.gz0, gzn = CORR ? g.nz : g.gnz;
     auto plane_of = [&](int p) { return (long long)min(max(p, -zhalo), g.nz - 1 + zhalo) * g.plane; };
 
     // ---- on-the-fly prolongation (CORR) ------------------------------------------------------
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
         // planes outside the grid (p = -1 or nz, first / last chunk only) are never evaluated: their
         // v only feeds Dirichlet outputs, and the wave-edge load of row 0 on plane -1 would fall
         // in front of the allocation
-        const bool pin = (g.gz0 + p >= 0) && (g.gz0 + p < g.gnz);  // a plane of the global grid
+        const bool pin = (gzo + p >= 0) && (gzo + p < gzn);  // a plane of the global grid
         vec b[TYV], v[TYV];
         T vtail[TYV];
 #pragma unroll
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
         }
         publish_edges((p + 1) & 1, up, ter_n);
         if (pin) {
-            const bool zbp = (g.gz0 + p == 0) || (g.gz0 + p == g.gnz - 1);
+            const bool zbp = (gzo + p == 0) || (gzo + p == gzn - 1);
 #pragma unroll
             for (int r = 0; r < TYV; r++) {
                 // x-neighbours across the wave edges: the neighbouring wave's edge element of plane p
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
                     T jac = quo[e];
                     if (DAMPED) jac = uc[r][e] + omega * (jac - uc[r][e]);
                     v[r][e] = (rb || (x0 + e == 0)) ? b[r][e] : jac;
-                    if (RB && (((x0 + e + y0 - 1 + r + g.gz0 + p) & 1) != 0)) v[r][e] = uc[r][e];  // not red: unchanged
+                    if (RB && (((x0 + e + y0 - 1 + r + gzo + p) & 1) != 0)) v[r][e] = uc[r][e];  // not red: unchanged
                 }
                 // v(p) goes to its LDS slot at once (the slot held v(p-2), last read before the previous
                 // barrier): the registers of v rows 0 and TYV-1 and of vtail are free for the second sweep
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
         // ---- second sweep on plane q = p-1
         const int q = p - 1;
         if (q >= z0 && q < z1) {
-            const bool zbq = (g.gz0 + q == 0) || (g.gz0 + q == g.gnz - 1);
+            const bool zbq = (gzo + q == 0) || (gzo + q == gzn - 1);
             const int sl = q & 1;
             const long long qo = (long long)q * g.plane;
 #pragma unroll
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
                         T jac = quo[e];
                         if (DAMPED) jac = vc[r][e] + omega * (jac - vc[r][e]);
                         res[e] = (rb || (x0 + e == 0)) ? bq[r][e] : jac;
-                        if (RB && (((x0 + e + y + g.gz0 + q) & 1) == 0)) res[e] = vc[r][e];  // not black: unchanged
+                        if (RB && (((x0 + e + y + gzo + q) & 1) == 0)) res[e] = vc[r][e];  // not black: unchanged
                     }
                     __builtin_nontemporal_store(res, (vec *)((out + (qo + urow[lr])) + x0));
                     if (tailwave && lane >= 56) {
@@ -711,15 +715,14 @@ bool jacobi2_slab_ok(const Geom &g)
 }
 
 template <typename T>
-void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out, bool zero_u,
-                    int zhalo)
+void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out, bool zero_u)
 {
     constexpr int V = VecOf<T>::V;
     const int tpr = (g.nx - 1) / V;
     const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
-#define MG_J2K(TPR, D, N, Z) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}, zhalo)
+#define MG_J2K(TPR, D, N, Z) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{})
 #define MG_J2(TPR) \
     do { \
         if (zero_u) { if (damped) MG_J2K(TPR, true, false, true); else MG_J2K(TPR, false, false, true); } \
@@ -750,8 +753,8 @@ void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
 #define MG_RB2(TPR) \
     do { \
-        if (coarse) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, coarse, gc, 1); \
-        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}, 1); \
+        if (coarse) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, coarse, gc); \
+        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
     } while (0)
     if (tpr == 256) MG_RB2(256); else if (tpr == 128) MG_RB2(128); else MG_RB2(64);
 #undef MG_RB2
@@ -781,8 +784,8 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
     const bool damped = (omega != (T)1);
 #define MG_J2C(TPR) \
     do { \
-        if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 1); \
-        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 1); \
+        if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
+        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
     } while (0)
     if (tpr == 256) MG_J2C(256); else if (tpr == 128) MG_J2C(128); else MG_J2C(64);
 #undef MG_J2C
@@ -794,10 +797,10 @@ template void launch_jacobi2_corr<double>(hipStream_t, const Geom &, const Geom 
 template void launch_jacobi2_corr<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, float, const float *, const float *, const float *, float *);
 template bool jacobi2_ok<double>(const Geom &);
 template bool jacobi2_ok<float>(const Geom &);
-template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *, bool, int);
+template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *, bool);
 template bool jacobi2_slab_ok<double>(const Geom &);
 template bool jacobi2_slab_ok<float>(const Geom &);
-template void launch_jacobi2<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *, bool, int);
+template void launch_jacobi2<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *, bool);
 template bool fast_path_ok<double>(const Geom &);
 template bool fast_path_ok<float>(const Geom &);
 template int fast_partials_capacity<double>(const Geom &);

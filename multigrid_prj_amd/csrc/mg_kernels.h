@@ -28,8 +28,8 @@ void launch_jacobi_fast(hipStream_t s, const Geom &g, const Coef<T> &c, T omega,
 template <typename T> bool jacobi2_ok(const Geom &g);
 template <typename T>
 void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out,
-                    bool zero_u = false, int zhalo = 1);
-// z-slab of a distributed level: the pair on its inner planes (g = planes 1 .. nz-2, zhalo = 2), see pair_on_slab_t
+                    bool zero_u = false);
+// z-slab of a distributed level: the pair on its inner planes (launch_jacobi2 with g = planes 1 .. nz-2), see pair_on_slab_t
 template <typename T> bool jacobi2_slab_ok(const Geom &slab);
 // the same with the V-cycle's prolong-add folded in: out = J(J(u + P coarse)); u is not modified
 template <typename T> bool jacobi2_corr_ok(const Geom &gf, const Geom &gc);

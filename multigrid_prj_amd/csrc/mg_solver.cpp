@@ -567,7 +567,7 @@ int Solver::pair_on_slab_t(int level)
     launch_jacobi<T>(stream_, ghi, c, om, px + ohi, pr + ohi, pv + ohi, false);
     MG_TRY(exchange_begin(MG_ARR_E, level));
     Geom gb = g; gb.nz = g.nz - 2; gb.gz0 = g.gz0 + 1;
-    launch_jacobi2<T>(stream_, gb, c, om, px + pl, pr + pl, pt + pl, false, 2);
+    launch_jacobi2<T>(stream_, gb, c, om, px + pl, pr + pl, pt + pl, false);
     MG_TRY(exchange_end());
     Geom g0 = g; g0.nz = 1;
     launch_jacobi<T>(stream_, g0, c, om, pv, pr, pt, false);
