@@ -541,7 +541,13 @@ bool Solver::can_fold_prolong(int level) const
            jacobi2_corr_ok<T>(lv_[level].g, lv_[level + 1].g);
 }
 
-// Two Jacobi sweeps of U on a z-slab with the fused kernel (depth-1 ghost planes are enough):
+static bool rb_slab_enabled()
+{
+    static const bool e = [] { const char *v = getenv("MG_FUSED_RB"); return !(v && v[0] == '0'); }();
+    return e;
+}
+
+// Two Jacobi sweeps (or, rb, the two colour passes of one red-black sweep) of U on a z-slab with the fused kernel (depth-1 ghost planes are enough):
 //   a. halo of u;
 //   b. sweep 1 on the two outermost planes of either end -> v in the level's E array (free in a
 //      V-cycle), and the halo of v starts moving on the communication stream;
@@ -550,7 +556,7 @@ bool Solver::can_fold_prolong(int level) const
 //   d. sweep 2 on planes 0 and nz-1 from v once its ghosts are in.
 // Same arithmetic per point as two exchanged single sweeps => same bits as one GPU.
 template <typename T>
-int Solver::pair_on_slab_t(int level)
+int Solver::pair_on_slab_t(int level, bool rb)
 {
     Level &L = lv_[level];
     const Geom &g = L.g;
@@ -559,21 +565,27 @@ int Solver::pair_on_slab_t(int level)
     T *px = ptr<T>(MG_ARR_U, level), *pr = ptr<T>(MG_ARR_RHS, level), *pt = ptr<T>(MG_ARR_TMP, level),
       *pv = ptr<T>(MG_ARR_E, level);
     const long long pl = g.plane;
+    // rb: the "pair" is one red-black sweep -- first pass = red half-sweep, second pass = black half-sweep
+    auto pass = [&](int which, const Geom &gs, const T *in, const T *rhs, T *out) {
+        if (rb) launch_rb_fast<T>(stream_, gs, c, which, in, rhs, out);
+        else launch_jacobi<T>(stream_, gs, c, om, in, rhs, out, false);
+    };
     MG_TRY(exchange(MG_ARR_U, level));
     Geom glo = g; glo.nz = 2;
-    launch_jacobi<T>(stream_, glo, c, om, px, pr, pv, false);
+    pass(0, glo, px, pr, pv);
     Geom ghi = g; ghi.nz = 2; ghi.gz0 = g.gz0 + g.nz - 2;
     const long long ohi = (long long)(g.nz - 2) * pl;
-    launch_jacobi<T>(stream_, ghi, c, om, px + ohi, pr + ohi, pv + ohi, false);
+    pass(0, ghi, px + ohi, pr + ohi, pv + ohi);
     MG_TRY(exchange_begin(MG_ARR_E, level));
     Geom gb = g; gb.nz = g.nz - 2; gb.gz0 = g.gz0 + 1;
-    launch_jacobi2<T>(stream_, gb, c, om, px + pl, pr + pl, pt + pl, false);
+    if (rb) launch_rb_fused<T>(stream_, gb, c, px + pl, pr + pl, pt + pl, (const T *)nullptr, gb);
+    else launch_jacobi2<T>(stream_, gb, c, om, px + pl, pr + pl, pt + pl, false);
     MG_TRY(exchange_end());
     Geom g0 = g; g0.nz = 1;
-    launch_jacobi<T>(stream_, g0, c, om, pv, pr, pt, false);
+    pass(1, g0, pv, pr, pt);
     Geom g1 = g; g1.nz = 1; g1.gz0 = g.gz0 + g.nz - 1;
     const long long o1 = (long long)(g.nz - 1) * pl;
-    launch_jacobi<T>(stream_, g1, c, om, pv + o1, pr + o1, pt + o1, false);
+    pass(1, g1, pv + o1, pr + o1, pt + o1);
     MG_HIP(hipGetLastError());
     std::swap(L.base[MG_ARR_U], L.base[MG_ARR_TMP]);
     return MG_OK;
@@ -600,7 +612,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
         for (int s = 0; s < sweeps; s++) {
             if (L.dist && overlap_ && d_.cycle == MG_CYCLE_V && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps &&
                 !(x_zero && s == 0) && jacobi2_slab_ok<T>(L.g)) {  // E is free in a V-cycle: scratch for the boundary planes' first sweep
-                MG_TRY(pair_on_slab_t<T>(level));
+                MG_TRY(pair_on_slab_t<T>(level, false));
                 s++;
                 continue;
             }
@@ -631,6 +643,11 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
         break;
     case MG_SMOOTH_RBGS:
         for (int s = 0; s < sweeps; s++) {
+            if (L.dist && overlap_ && d_.cycle == MG_CYCLE_V && ax == MG_ARR_U && ar == MG_ARR_RHS &&
+                jacobi2_slab_ok<T>(L.g) && rb_slab_enabled()) {  // one-pass red-black sweep on the slab's inner planes
+                MG_TRY(pair_on_slab_t<T>(level, true));
+                continue;
+            }
             if (!L.dist && rb_fused_ok<T>(L.g)) {  // both colours in one pass over HBM; the sweep lands in TMP
                 const bool corr = (s == 0 && corr_level >= 0);
                 launch_rb_fused<T>(stream_, L.g, c, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),

@@ -88,7 +88,7 @@ private:
     template <typename T> int smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero = false,
                                        int corr_level = -1);
     template <typename T> bool can_fold_prolong(int level) const;
-    template <typename T> int pair_on_slab_t(int level);
+    template <typename T> int pair_on_slab_t(int level, bool rb);
     template <typename T> bool can_skip_zeroing(int level) const;
     template <typename T> int residual_t(int level, int ax, int ar, int arr_r, bool want_norm);
     template <typename T> int sumsq_t(int level, int arr);

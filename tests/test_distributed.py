@@ -52,12 +52,14 @@ def _run_ranks(mode, world, case, tmp_path, timeout=600):
     return np.concatenate([p["u"] for p in parts], axis=0), [p["hist"] for p in parts], int(parts[0]["fg"])
 
 
-def _case(tmp_path, n, levels, restriction, cycles=2, semi=0, zebra=False):
+def _case(tmp_path, n, levels, restriction, cycles=2, semi=0, zebra=False, rb=False):
     desc = dict(dim=3, n=n, levels=levels, dtype=0, length=1.0, alpha=1.0, cycle=1, smoother=1, omega=6 / 7,
                 nu_pre=2, nu_post=2, restriction=restriction, coarse_mode=1, coarse_maxit=20, outer_pre_gs=0,
                 dist_min_n=33)
     if semi:  # eps = 0.25 -> one semi-coarsening (log4(1/eps) = 1), then standard coarsening
         desc.update(semi_xy=1, aniso=(1.0, 1.0, 0.25), omega=0.8, coarse_maxit=80)
+    if rb:
+        desc.update(smoother=2, omega=1.0)
     if zebra:  # strong y-coupling, zebra lines along y (they never cross the z-slabs)
         desc.update(smoother=3, omega=1.0, aniso=(1.0, 50.0, 1.0))
     b = po.fill_rhs_3d(n, 1.0, 1.0, 1)
@@ -130,6 +132,25 @@ def test_hip_distributed_semi_coarsening(world, n, levels, tmp_path):
     for h in hists:
         np.testing.assert_allclose(h, h1, rtol=1e-12)
     assert h1[-1] < 0.5 * h1[-2]  # the mixed hierarchy keeps multigrid convergence (coarse grid only swept)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,levels", [(2, 65, 3), (3, 129, 3), (2, 257, 4)])
+def test_hip_distributed_red_black(world, n, levels, tmp_path):
+    """Red-black Gauss-Seidel on slabs: colour passes on narrow levels, the one-pass sweep on the inner
+    planes of wide ones (n >= 129) with the boundary planes' red pass exchanged under it."""
+    from multigrid_prj_amd import capi
+    case, desc, b = _case(tmp_path, n, levels, 1, rb=True)
+    u, hists, fg = _run_ranks("hip", world, case, tmp_path)
+    with capi.Solver(capi.make_desc(**desc)) as s:
+        s.set_rhs(b)
+        for _ in range(case["cycles"]):
+            s.cycle()
+        h1, _ = s.solve(0.0, 2)
+        u1 = s.get_solution()
+    assert np.array_equal(u, u1)
+    u_ref, h_ref = _oracle(desc, b, case["cycles"])
+    assert np.array_equal(u, u_ref)
 
 
 @pytest.mark.gpu
