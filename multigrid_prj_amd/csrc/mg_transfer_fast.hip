@@ -408,7 +408,7 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
                               const T *rhs, T *coarse)
 {
     constexpr int CV = PV<T>::V / 2;
-    constexpr int CR = 1;                                     // coarse rows per workgroup (2 measured slower: 156 VGPRs)
+    constexpr int CR = 1;                                     // coarse rows per workgroup (2 measured slower again after the mailbox change: 185 VGPRs, 3.28 vs 3.10 ms per cycle)
     const int ncol = gc.nx - 1;                               // coarse columns owned by lanes
     const int nw = (ncol + 64 * CV - 1) / (64 * CV);          // waves side by side in x (<= 8)
     const int nby = (gc.ny + CR - 1) / CR;
