@@ -52,6 +52,7 @@ public:
     int init();  // allocates; returns mg_status
 
     int set_array(int which, int level, const void *host);
+    int stage_rows(int which, int level, void *host, bool to_device);
     int get_array(int which, int level, void *host);
     int zero_array(int which, int level);
 
@@ -138,6 +139,8 @@ private:
     int rank_ = 0, nranks_ = 1, T_ = -1;
     hipStream_t comm_stream_ = nullptr;
     hipEvent_t ev_ready_ = nullptr, ev_halo_ = nullptr;
+    void *h_stage_ = nullptr;      // pinned staging buffer of set_array / get_array
+    size_t h_stage_bytes_ = 0;
     bool overlap_ = true;  // MG_OVERLAP=0 disables (debugging)
     Geom gfull_{};
     void *full_[3] = {nullptr, nullptr, nullptr};
