@@ -1023,13 +1023,16 @@ __global__ __launch_bounds__(256) void k_zebra_y(Geom g, Coef<T> c, int colour, 
     const int x = 2 * (blockIdx.x * 64 + threadIdx.x) + ((colour + gz) & 1);
     if (x >= g.nx) return;
     const long long base = (long long)z * g.plane + x, sj = g.pitch;
+    // dp is scratch: stored packed (x / 2), so that the active colour's lanes write and read whole lines
+    // (in the interleaved u array every other element belongs to the other colour)
+    const long long dbase = (long long)z * g.plane + (x >> 1);
     const int ny = g.ny;
     if (x == 0 || x == g.nx - 1 || (DIM == 3 && (gz == 0 || gz == g.gnz - 1))) {
         for (int j = 0; j < ny; j++) u[base + j * sj] = rhs[base + j * sj];  // identity rows: u = b / 1
         return;
     }
     T dprev = rhs[base];
-    dp[base] = dprev;
+    dp[dbase] = dprev;
     for (int j0 = 1; j0 < ny - 1; j0 += U) {
         T R[U], dn[U];
 #pragma unroll
@@ -1048,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_zebra_y(Geom g, Coef<T> c, int colour, 
         for (int k = 0; k < U; k++) {
             if (j0 + k < ny - 1) {
                 dprev = (R[k] - c.cy * dprev) / dn[k];
-                dp[base + (j0 + k) * sj] = dprev;
+                dp[dbase + (j0 + k) * sj] = dprev;
             }
         }
     }
@@ -1059,7 +1062,7 @@ __global__ __launch_bounds__(256) void k_zebra_y(Geom g, Coef<T> c, int colour, 
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const int j = max(j0 - k, 1);
-            D[k] = dp[base + j * sj];
+            D[k] = dp[dbase + j * sj];
             C[k] = cp[j];
         }
 #pragma unroll
@@ -1070,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_zebra_y(Geom g, Coef<T> c, int colour, 
             }
         }
     }
-    u[base] = dp[base];
+    u[base] = dp[dbase];
 }
 
 inline dim3 grid_for(int nx, int ny, int nz)
