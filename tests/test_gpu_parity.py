@@ -185,6 +185,8 @@ VC = [
          aniso=(1.0, 100.0, 1.0)),
     dict(dim=2, n=129, levels=5, dtype=capi.MG_F64, smoother=capi.SMOOTH_ZEBRA_Y, omega=1.0, restriction=capi.RESTRICT_FULLW,
          aniso=(1.0, 100.0, 1.0)),
+    dict(dim=3, n=65, levels=4, dtype=capi.MG_F32, smoother=capi.SMOOTH_ZEBRA_Y, omega=1.0, restriction=capi.RESTRICT_FULLW,
+         aniso=(1.0, 30.0, 1.0)),
     # red-black with the fused one-pass sweep and the prolongation folded into the first post-sweep
     dict(dim=3, n=129, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_RBGS, omega=1.0, restriction=capi.RESTRICT_FULLW),
     dict(dim=3, n=257, levels=5, dtype=capi.MG_F32, smoother=capi.SMOOTH_RBGS, omega=1.0, restriction=capi.RESTRICT_FULLW),
@@ -220,7 +222,9 @@ def test_vcycle_extension(case):
         # (The 33 x 33 x 65 coarsest grid of the n=129 semi case is only swept 30 times, far from
         # solved: it checks the swept-coarse-level path bit for bit, not its convergence.)
         swept_coarse = case.get("semi_xy") and case["n"] == 129
-        if not (case["smoother"] == capi.SMOOTH_RBGS and case.get("restriction", 0) == capi.RESTRICT_INJECT) and not swept_coarse:
+        at_floor = case["dtype"] == capi.MG_F32 and hg[0] < 1e-5   # fp32 round-off floor reached within the first cycles
+        if not (case["smoother"] == capi.SMOOTH_RBGS and case.get("restriction", 0) == capi.RESTRICT_INJECT) and not swept_coarse \
+                and not at_floor:
             assert hg[-1] < 0.2 * hg[0]
 
 
