@@ -205,7 +205,10 @@ def main():
                      "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "sweep_ms": sweep_ms, "sweeps_timed": sm_sweeps,
-                     "algorithmic_bytes_per_sweep": bytes_per_sweep},
+                     "algorithmic_bytes_per_sweep": bytes_per_sweep,
+                     "note": ("temporal blocking: one launch performs two sweeps in one pass over HBM, so the algorithmic "
+                              "two-sweep bytes per launch can exceed what a streaming kernel could move; `traffic` is the "
+                              "measured fabric-side traffic of that launch" if fused_pair else None)},
         "smoother_gbps": achieved,
         # one launch = prolong-add (read u, read coarse, write u: not executed as such) + two sweeps
         "prolong_folded_pair": ({"kernel": ("k_jacobi2<CORR>: J(J(u + P e)) in one pass" if a.smoother == "jacobi"

@@ -262,12 +262,12 @@ static int j2_nbz(const Geom &g)
 // half-sweep on the plane behind (black points updated from phase 1's values, red points
 // copied): out = RB(u) in one pass over HBM instead of two (k_sweep3d<OP_RB> twice).
 // ZEROU: u is identically zero (the two pre-smoothing sweeps of a coarse level): nothing is loaded for it.
-template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false, bool ZEROU = false>
+template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false, bool ZEROU = false, int TYO_ = J2_TYO>
 __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
                                                  const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz,
                                                  const T *__restrict__ coarse, Geom gc)
 {
-    constexpr int V = VecOf<T>::V, TYO = J2_TYO, TYV = TYO + 2;
+    constexpr int V = VecOf<T>::V, TYO = TYO_, TYV = TYO + 2;
     constexpr int CV = V / 2;  // coarse columns owned by this thread
     static_assert(!CORR || TYO == 2, "the correction assumes two output rows (y0 even)");
     constexpr int LP = TPR * V + 2 * V;  // LDS row: V pad | TPR*V values | tail column | pad
@@ -722,7 +722,15 @@ void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, con
     const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
-#define MG_J2K(TPR, D, N, Z) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{})
+    // three output rows per workgroup where the correction is not folded in: 5 instead of 4 first-sweep rows
+    // per 3 instead of 2 outputs, 167 VGPRs (still 3 workgroups/CU): 0.86 -> 0.79 ms per pair at 513^3
+    static const int tyo = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
+    const int nby3 = (g.ny + 2) / 3, grid3 = ((nby3 * nbz + 7) / 8) * 8;
+#define MG_J2K(TPR, D, N, Z) \
+    do { \
+        if (tyo == 3) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z, 3>), dim3(grid3), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}); \
+        else hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
+    } while (0)
 #define MG_J2(TPR) \
     do { \
         if (zero_u) { if (damped) MG_J2K(TPR, true, false, true); else MG_J2K(TPR, false, false, true); } \
@@ -751,9 +759,12 @@ void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
     const int tpr = (g.nx - 1) / V;
     const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
+    static const int tyo = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
+    const int nby3 = (g.ny + 2) / 3, grid3 = ((nby3 * nbz + 7) / 8) * 8;
 #define MG_RB2(TPR) \
     do { \
         if (coarse) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, coarse, gc); \
+        else if (tyo == 3) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true, false, 3>), dim3(grid3), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}); \
         else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
     } while (0)
     if (tpr == 256) MG_RB2(256); else if (tpr == 128) MG_RB2(128); else MG_RB2(64);
