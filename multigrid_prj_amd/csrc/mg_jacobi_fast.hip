@@ -236,19 +236,15 @@ __global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
 // boundaries travel through a small LDS mailbox one plane ahead (uedge / utail). Same per-point
 // arithmetic as two k_sweep3d launches => bit-identical; 0.85 ms against 2 x 0.60 ms per pair at
 // 513^3 fp64 (3 workgroups per CU; DESIGN.md section 4 has the history).
-constexpr int J2_TYO = 2, J2_ZC = 16;
+constexpr int J2_TYO = 2;
 // z-chunks per launch. Long marches amortise the two extra planes of first-sweep work per chunk,
-// short ones give the smaller levels enough workgroups to fill 256 CUs x 3: 16 planes at 513^3
-// (8481 workgroups; 8 is 5 % slower, 32 equal), 8 at 257^3 (4257; 16 is 6 % slower per cycle).
+// short ones give the smaller levels enough workgroups to fill 256 CUs x 3. Measured per V-cycle:
+// 513^3: 24 planes (16: +1.2 %, 32: +2 %, 8: +5 %); 257^3: 8 (16: +6 %, 4: +3 %); 129^3: 4 (8: +3 %).
 static int j2_nbz(const Geom &g)
 {
     static const int zc_env = [] { const char *e = getenv("MG_J2_ZC"); return e ? atoi(e) : 0; }();
-    int zc = J2_ZC;
+    int zc = g.nz >= 400 ? 24 : (g.nz >= 200 ? 8 : 4);
     if (zc_env > 1) zc = zc_env;
-    else {
-        const int nby = (g.ny + J2_TYO - 1) / J2_TYO;
-        while (zc > 4 && nby * ((g.nz + zc - 1) / zc) < 4000) zc >>= 1;
-    }
     return (g.nz + zc - 1) / zc;
 }
 
