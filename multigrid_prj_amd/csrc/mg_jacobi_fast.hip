@@ -240,15 +240,16 @@ constexpr int J2_TYO = 2;
 // z-chunks per launch. Long marches amortise the two extra planes of first-sweep work per chunk,
 // short ones give the smaller levels enough workgroups to fill 256 CUs x 3. Measured per V-cycle:
 // 513^3: 24 planes (16: +1.2 %, 32: +2 %, 8: +5 %); 257^3: 8 (16: +6 %, 4: +3 %); 129^3: 4 (8: +3 %);
-// the rule below gives 24 / 6 / 4 there.
+// the rule below gives 24 / 8 / 3 there.
 static int j2_nbz(const Geom &g)
 {
     static const int zc_env = [] { const char *e = getenv("MG_J2_ZC"); return e ? atoi(e) : 0; }();
-    int zc = 24;  // halved until the launch has enough workgroups (semi-coarsened levels: long in z, few rows)
+    int zc = 3;  // the longest march that still leaves enough workgroups (semi-coarsened levels: long in z, few rows)
     if (zc_env > 1) zc = zc_env;
     else {
         const int nby = (g.ny + 2) / 3;
-        while (zc > 4 && nby * ((g.nz + zc - 1) / zc) < 2800) zc = (zc + 1) / 2;
+        for (int cand : {24, 16, 12, 8, 6, 4})
+            if (nby * ((g.nz + cand - 1) / cand) >= 2800) { zc = cand; break; }
     }
     return (g.nz + zc - 1) / zc;
 }
