@@ -448,9 +448,8 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
     for (int p = z0 - 1; p <= z1; p++) {
         const long long po = plane_of(p);
         const T *pu = u + po;
-        // planes outside the grid (p = -1 or nz, first / last chunk only) are never evaluated: their
-        // v only feeds Dirichlet outputs, and the wave-edge load of row 0 on plane -1 would fall
-        // in front of the allocation
+        // planes outside the global grid (first / last chunk only) are never evaluated: their v only
+        // feeds Dirichlet outputs and stays zero
         const bool pin = (gzo + p >= 0) && (gzo + p < gzn);  // a plane of the global grid
         vec b[TYV], v[TYV];
         T vtail[TYV];
