@@ -447,6 +447,103 @@ __global__ __launch_bounds__(SWG) void k_gs_lex2d_rows(Geom g, Coef<T> c, int sw
     }
 }
 
+// Two lexicographic sweeps in ONE wavefront pass (the reference's `u * GS * GS`, main.cpp:85,95): the
+// second sweep follows the first two anti-diagonals behind, so at step d thread y updates point
+// x1 = d - y of sweep 1 and point x2 = d - 2 - y of sweep 2. Everything sweep 2 needs is one step old
+// and lives in registers: new2(y-1, x2) and new1(y+1, x2) are the neighbouring lanes' results of the
+// previous step (DPP, mailboxes across waves), new2(y, x2-1) and new1(y, x2+1) the thread's own.
+// Sweep 1's values never go to memory: half the steps and half the stores of two separate sweeps.
+template <typename T>
+__device__ __forceinline__ T gs_next_lane(T v, T edge);
+template <>
+__device__ __forceinline__ float gs_next_lane<float>(float v, float edge)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+template <>
+__device__ __forceinline__ double gs_next_lane<double>(double v, double edge)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <typename T, int PF>
+__global__ __launch_bounds__(SWG) void k_gs_lex2d_rows_pair(Geom g, Coef<T> c, T *u, const T *rhs)
+{
+    __shared__ T mail1[2][SWG / 64], mail2[2][SWG / 64], mailn[2][SWG / 64];
+    const int y = threadIdx.x, lane = y & 63, wv = y >> 6, nwv = (int)(blockDim.x >> 6);
+    const int nx = g.nx, ny = g.ny;
+    const bool rowin = y < ny;
+    const bool rowb = (y == 0) || (y == ny - 1);
+    const long long ro = (long long)min(y, ny - 1) * g.pitch;
+    const long long rdn = (long long)min(y + 1, ny - 1) * g.pitch;
+    const int nd = nx + ny - 1 + 2;  // sweep 2 finishes two steps after sweep 1
+    T pb[PF], pdn[PF], prt[PF];
+    auto fetch = [&](int d, T &b, T &dn, T &rt) {  // sweep 1's operands that are not on the chain (old values)
+        const int x = min(max(d - y, 0), nx - 1);
+        b = rhs[ro + x];
+        dn = u[rdn + x];
+        rt = u[ro + min(x + 1, nx - 1)];
+    };
+#pragma unroll
+    for (int j = 0; j < PF; j++) fetch(j, pb[j], pdn[j], prt[j]);
+    T mine1 = 0, pub1 = 0;       // sweep 1: own previous result (= new1(y, x1-1)); published value
+    T mine2 = 0, pub2 = 0;       // sweep 2 likewise
+    T bh1 = 0, bh2 = 0;          // rhs(y, x1) of the last two steps: sweep 2 needs rhs(y, x2) = the one of step d-2
+    for (int d0 = 0; d0 < nd; d0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            const int d = d0 + j, x1 = d - y, x2 = d - 2 - y;
+            // neighbours' results of the previous step (read before anything of this step is published)
+            T w1 = 0, w2 = 0, wn = 0;
+            if (lane == 0 && wv > 0) { w1 = mail1[(d + 1) & 1][wv - 1]; w2 = mail2[(d + 1) & 1][wv - 1]; }
+            if (lane == 63 && wv < nwv - 1) wn = mailn[(d + 1) & 1][wv + 1];
+            const T up1 = gs_prev_lane<T>(pub1, w1);   // new1(y-1, x1)
+            const T up2 = gs_prev_lane<T>(pub2, w2);   // new2(y-1, x2)
+            const T dn2 = gs_next_lane<T>(pub1, wn);   // new1(y+1, x2): thread y+1's sweep-1 result of step d-1
+            const T rt2 = pub1;                        // new1(y, x2+1): own sweep-1 result of step d-1
+            const T b1 = pb[j];
+            T val1 = pub1, val2 = pub2;
+            if (rowin && x1 >= 0 && x1 < nx) {
+                if (rowb || x1 == 0 || x1 == nx - 1) {
+                    val1 = b1;
+                } else {
+                    T sum = 0;
+                    sum += c.cy * up1;
+                    sum += c.cx * mine1;
+                    sum += c.cx * prt[j];
+                    sum += c.cy * pdn[j];
+                    val1 = div_cd<T>(b1 - sum, c);
+                }
+                mine1 = val1;
+            }
+            if (rowin && x2 >= 0 && x2 < nx) {
+                if (rowb || x2 == 0 || x2 == nx - 1) {
+                    val2 = bh2;
+                } else {
+                    T sum = 0;
+                    sum += c.cy * up2;
+                    sum += c.cx * mine2;
+                    sum += c.cx * rt2;
+                    sum += c.cy * dn2;
+                    val2 = div_cd<T>(bh2 - sum, c);
+                }
+                u[ro + x2] = val2;
+                mine2 = val2;
+            }
+            pub1 = val1; pub2 = val2;
+            bh2 = bh1; bh1 = b1;
+            if (lane == 63) { mail1[d & 1][wv] = val1; mail2[d & 1][wv] = val2; }
+            if (lane == 0) mailn[d & 1][wv] = val1;
+            fetch(d + PF, pb[j], pdn[j], prt[j]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+    }
+}
+
 template <typename T, int DIM>
 __device__ double wg_residual_sumsq(const Geom &g, const Coef<T> &c, const T *u, const T *rhs,
                                     double *sh)
@@ -1124,10 +1221,18 @@ void launch_gs_lex(hipStream_t s, const Geom &g, const Coef<T> &c, int sweeps, T
     if (g.dim == 3) hipLaunchKernelGGL((k_gs_lex<T, 3>), dim3(1), dim3(SWG), 0, s, g, c, sweeps, u, rhs);
     else if (rows && g.ny <= SWG && g.nx >= 3 && g.ny >= 3) {  // one thread per row
         static const int pf = [] { const char *e = getenv("MG_GS_PF"); return e ? atoi(e) : 4; }();
+        static const bool pairs = [] { const char *e = getenv("MG_GS_PAIR"); return !(e && e[0] == '0'); }();
         const dim3 bl(((g.ny + 63) / 64) * 64);
-        if (pf == 16) hipLaunchKernelGGL((k_gs_lex2d_rows<T, 16>), dim3(1), bl, 0, s, g, c, sweeps, u, rhs);
-        else if (pf == 8) hipLaunchKernelGGL((k_gs_lex2d_rows<T, 8>), dim3(1), bl, 0, s, g, c, sweeps, u, rhs);
-        else hipLaunchKernelGGL((k_gs_lex2d_rows<T, 4>), dim3(1), bl, 0, s, g, c, sweeps, u, rhs);
+        int left = sweeps;
+        while (pairs && left >= 2) {  // two sweeps per wavefront pass
+            hipLaunchKernelGGL((k_gs_lex2d_rows_pair<T, 4>), dim3(1), bl, 0, s, g, c, u, rhs);
+            left -= 2;
+        }
+        if (left > 0) {
+            if (pf == 16) hipLaunchKernelGGL((k_gs_lex2d_rows<T, 16>), dim3(1), bl, 0, s, g, c, left, u, rhs);
+            else if (pf == 8) hipLaunchKernelGGL((k_gs_lex2d_rows<T, 8>), dim3(1), bl, 0, s, g, c, left, u, rhs);
+            else hipLaunchKernelGGL((k_gs_lex2d_rows<T, 4>), dim3(1), bl, 0, s, g, c, left, u, rhs);
+        }
     }
     else hipLaunchKernelGGL((k_gs_lex<T, 2>), dim3(1), dim3(SWG), 0, s, g, c, sweeps, u, rhs);
 }
