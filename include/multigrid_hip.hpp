@@ -6,8 +6,10 @@
 // Same class names, constructor arguments, `apply_iteration_to_vec(std::vector<double>&)`
 // and `x * Op` chaining as the reference (paths relative to
 // /root/reference/GeometricMultigrid/: include/domain.hpp, include/linear_system.hpp,
-// include/solvers.hpp, include/multigrid.hpp), so the reference's main.cpp compiles
-// against this header unchanged apart from the include line.  Host std::vectors stay the
+// include/solvers.hpp, include/multigrid.hpp), so the reference's src/main.cpp compiles and
+// links against this header unchanged apart from the umbrella include (checked by
+// tests/test_cli_and_mirror.py::test_reference_main_cpp_builds_against_the_mirror, which
+// compiles that file where it lies).  Host std::vectors stay the
 // source of truth exactly as in the reference: each operator application moves its level's
 // entries to HBM, runs the HIP kernels and moves them back.  That is the compatibility
 // path; whole solves should use DeviceSolve (below) / mg_solve, which keep every array
@@ -51,6 +53,7 @@ public:
     virtual std::tuple<size_t, size_t> meshIdx(size_t l) const = 0;
     virtual std::tuple<double, double> operator[](const size_t i) const = 0;
     virtual bool isOnBoundary(const size_t l) const = 0;
+    virtual std::vector<size_t> &inRowConnections(const size_t l) = 0;
     virtual std::array<size_t, 5> inRowConnections_a(const size_t l) = 0;
     virtual size_t mask(const size_t l) const = 0;
     virtual size_t getWidth() const = 0;
@@ -85,6 +88,14 @@ public:
         auto [i, j] = meshIdx(l);
         return i == 0 || j == 0 || i == m_size - 1 || j == m_size - 1;
     }
+    // domain.cpp:26-34: the row of the matrix as stored entries -- {l} alone on a Dirichlet row.
+    // Like the reference it answers through one member vector, so it is not re-entrant.
+    std::vector<size_t> &inRowConnections(const size_t l) override
+    {
+        if (isOnBoundary(mask(l))) m_vec = {l};
+        else m_vec = {l - m_width, l - 1, l, l + 1, l + m_width};
+        return m_vec;
+    }
     std::array<size_t, 5> inRowConnections_a(const size_t l) override { return {l - m_width, l - 1, l, l + 1, l + m_width}; }
     size_t mask(const size_t l) const override { return m_step * (l / m_width) * m_size + m_step * (l % m_width); }
     size_t getWidth() const override { return m_width; }
@@ -100,6 +111,7 @@ public:
 private:
     size_t m_size, m_step, m_level, m_width;
     double m_length, m_h;
+    std::vector<size_t> m_vec;
 };
 
 // ------------------------------------------------------------ include/linear_system.hpp
@@ -120,6 +132,7 @@ public:
         // the reference tests "row distance == step OR column distance == step" (:37-38)
         return (dr == 1 || dc == 1) ? -m_alpha / k : 0.;
     }
+    const std::vector<size_t> &nonZerosInRow(const size_t row) { return m_domain->inRowConnections(row); }  // :44-46
     const std::array<size_t, 5> nonZerosInRow_a(const size_t row) { return m_domain->inRowConnections_a(row); }
     size_t nonZeros() { return m_size + m_domain->numConnections(); }
     size_t mask(const size_t l) { return m_domain->mask(l); }
@@ -273,6 +286,27 @@ public:
     using detail::DeviceSmoother<Vector, MG_SMOOTH_JACOBI>::DeviceSmoother;
 };
 
+// solvers.hpp:86-216. The reference constructs a BiCGSTAB-smoothed cycle (main.cpp:56) and never
+// applies it: `-smt 2` prints "BiCGSTAB iters" and runs the Jacobi cycle MG1 (main.cpp:103-106);
+// the class itself mixes masked and unmasked indices (:157,175), SURVEY §8a. The mirror keeps the
+// type constructible with the reference's signature so that caller code compiles and links; no
+// kernel exists for it (and there is no CPU fallback), so applying it is refused loudly.
+template <class Vector>
+class BiCGSTAB : public SmootherClass<Vector> {
+public:
+    BiCGSTAB(PoissonMatrix<double> &A, Vector &f, double tolerance = TOL) : m_A(A), b(f), tol(tolerance) {}
+    void apply_iteration_to_vec(std::vector<double> &) override
+    {
+        throw std::logic_error("MultiGrid::BiCGSTAB: not on the GPU hot path -- the reference never applies it "
+                               "(src/main.cpp:103-106 runs the Jacobi cycle for -smt 2)");
+    }
+
+private:
+    PoissonMatrix<double> &m_A;
+    Vector &b;
+    double tol;
+};
+
 // solvers.hpp:219-308
 template <class Vector>
 class Residual {
@@ -406,6 +440,8 @@ namespace detail {
 template <class S> struct smoother_id;
 template <class V> struct smoother_id<Gauss_Seidel_iteration<V>> { static constexpr int value = MG_SMOOTH_GS_LEX; };
 template <class V> struct smoother_id<Jacobi_iteration<V>> { static constexpr int value = MG_SMOOTH_JACOBI; };
+// what the reference's driver runs when asked for the BiCGSTAB cycle (main.cpp:103-106: MG1)
+template <class V> struct smoother_id<BiCGSTAB<V>> { static constexpr int value = MG_SMOOTH_JACOBI; };
 }  // namespace detail
 
 // multigrid.hpp:88-158. The whole cycle (residual, injection, persistent coarse solve,

@@ -82,5 +82,27 @@ def build_mirror_harness(out_path: str, defines=()) -> str:
     return out_path
 
 
+REFERENCE_MAIN = "/root/reference/GeometricMultigrid/src/main.cpp"
+REFMAIN_PATH = os.path.join(ROOT, "tests", "cpp", "_build", "refmain_mirror")
+
+
+def build_reference_main(out_path: str = REFMAIN_PATH):
+    """Compiles AND LINKS the reference's own src/main.cpp -- where it lies under /root/reference,
+    nothing is copied -- against include/multigrid_hip.hpp + host/utilities.cpp + libmg_hip.so
+    (INTEGRATION.md §B). Returns None where the reference is not mounted (the GPU box): the binary
+    built in the container travels there with the snapshot."""
+    if not os.path.exists(REFERENCE_MAIN):
+        return out_path if os.path.exists(out_path) else None
+    build()
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    subprocess.run(["g++", "-std=c++20", "-O2", "-Wall", "-Wno-unused-parameter",
+                    "-I" + os.path.join(ROOT, "tests", "cpp", "shim"),
+                    "-I" + os.path.join(ROOT, "include"), "-I" + HOST,
+                    REFERENCE_MAIN, os.path.join(HOST, "utilities.cpp"),
+                    "-L" + LIB_DIR, "-lmg_hip", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib",
+                    "-o", out_path], check=True)
+    return out_path
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -35,7 +35,7 @@ void usage()
               << "  -smt, you can choose your favourite smoother" << std::endl
               << "  --help, Display this help message" << std::endl
               << "MI355X extensions:" << std::endl
-              << "  -dim 2|3, -cycle saw|v, -omega W, -nu1 K, -nu2 K, -rbgs, -zebra, -fw, -coarse_fixed K, -fp32, -maxit K, -eps E, -semi K" << std::endl;
+              << "  -dim 2|3, -cycle saw|v, -omega W, -nu1 K, -nu2 K, -rbgs, -zebra, -fw, -coarse_fixed K, -fp32, -maxit K, -cold, -eps E, -semi K" << std::endl;
 }
 
 }  // namespace
@@ -94,14 +94,23 @@ void Utils::parse_command_line(int argc, char **argv, Options &o)
         else if (a == "-nu1" && has_value) { o.nu1 = std::atoi(argv[i + 1]); }
         else if (a == "-nu2" && has_value) { o.nu2 = std::atoi(argv[i + 1]); }
         else if (a == "-coarse_fixed" && has_value) { o.coarse_fixed = std::atoi(argv[i + 1]); }
-        else if (a == "-maxit" && has_value) { o.maxit = std::atoi(argv[i + 1]); }
+        else if (a == "-maxit" && has_value) { o.maxit = std::atoi(argv[i + 1]); if (o.maxit < 0) fail("Please, insert a valid -maxit value"); }
         else if (a == "-eps" && has_value) { o.eps_z = std::atof(argv[i + 1]); }
         else if (a == "-semi" && has_value) { o.semi = std::atoi(argv[i + 1]); }
         else if (a == "-rbgs") { o.rbgs = true; }
         else if (a == "-zebra") { o.zebra = true; }  // zebra line Gauss-Seidel along y
         else if (a == "-fw") { o.full_weighting = true; }
         else if (a == "-fp32") { o.fp32 = true; }
+        else if (a == "-cold") { o.cold = true; }
     }
+}
+
+void Utils::Initialization_for_N(int argc, char **argv, size_t &N, double &alpha, double &width, int &level,
+                                 int &functions_to_test, SMOOTHERS &sm)
+{
+    Options o;
+    parse_command_line(argc, argv, o);
+    N = o.N; alpha = o.alpha; width = o.width; level = o.level; functions_to_test = o.test; sm = o.smoother;
 }
 
 void Utils::init_test_functions(std::function<double(const double, const double)> &f,

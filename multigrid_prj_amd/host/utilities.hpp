@@ -29,9 +29,9 @@ struct Options {
     int test = DEFAULT_TEST;
     SMOOTHERS smoother = DEFAULT_METHOD;
     // extensions (absent from the reference): -dim 3, -cycle v, -omega, -nu1, -nu2, -rbgs, -zebra,
-    // -fw, -coarse_fixed K, -fp32, -maxit, -eps E (z-coupling multiplier), -semi K (first K coarsenings in x,y only)
+    // -fw, -coarse_fixed K, -fp32, -maxit, -cold (no warm-up cycle before the solve timer), -eps E (z-coupling multiplier), -semi K (first K coarsenings in x,y only)
     int dim = 2;
-    bool vcycle = false, rbgs = false, zebra = false, full_weighting = false, fp32 = false;
+    bool vcycle = false, rbgs = false, zebra = false, full_weighting = false, fp32 = false, cold = false;
     double omega = 1.0, eps_z = 1.0;
     int semi = 0;
     int nu1 = 2, nu2 = -1, coarse_fixed = -1, maxit = 1000;
@@ -41,9 +41,28 @@ struct Options {
 // messages on stdout, exit(1) on error or --help).
 void parse_command_line(int argc, char **argv, Options &opt);
 
+// The reference's own entry point (include/utilities.hpp:25, src/utilities.cpp:3-132), so that its
+// src/main.cpp builds against this directory unchanged: the six reference flags through
+// parse_command_line (the extension flags are parsed too, but have nowhere to go in this signature).
+void Initialization_for_N(int argc, char **argv, size_t &N, double &alpha, double &width, int &level,
+                          int &functions_to_test, SMOOTHERS &sm);
+
 // (f, g) pairs of the reference table; an index outside 0..2 selects pair 0 with a warning.
 void init_test_functions(std::function<double(const double, const double)> &f,
                          std::function<double(const double, const double)> &g, int i);
+
+// include/utilities.hpp:27-41: "rows cols nonZeros", then one "i j a_ij" line per stored entry
+// (A.nonZerosInRow(i): five entries on an interior row, the diagonal alone on a Dirichlet row)
+template <class SpMat>
+void saveMatrixOnFile(SpMat A, const std::string &fileName)
+{
+    std::ofstream file(fileName, std::ofstream::trunc);
+    file << A.rows() << " " << A.cols() << " " << A.nonZeros() << std::endl;
+    for (size_t i = 0; i < A.rows(); i++) {
+        const std::vector<size_t> row = A.nonZerosInRow(i);
+        for (const auto &j : row) file << i << " " << j << " " << A.coeffRef(i, j) << std::endl;
+    }
+}
 
 // first line = element count, then one value per line, default ostream precision
 template <class Vector>

@@ -89,6 +89,86 @@ def test_cmake_target_multigrid_configures_and_builds(tmp_path):
     assert (b / "bin" / "Multigrid").exists() and (b / "lib" / "libmg_hip.so").exists()
 
 
+def test_reference_main_cpp_builds_against_the_mirror(tmp_path):
+    """SURVEY §8b-2 / INTEGRATION.md B: the reference's OWN src/main.cpp, compiled where it lies, builds
+    and links against include/multigrid_hip.hpp + host/utilities.cpp + libmg_hip.so -- including
+    Utils::Initialization_for_N (main.cpp:16) and the never-applied BiCGSTAB cycle (main.cpp:56).
+    Container only: the reference does not exist on the GPU box."""
+    if not os.path.exists(mgbuild.REFERENCE_MAIN):
+        pytest.skip("/root/reference is not mounted here")
+    exe = mgbuild.build_reference_main(str(tmp_path / "refmain"))
+    assert exe and os.path.exists(exe)
+    rc, out = run_cli(exe, ["--help"], tmp_path)   # host-only path of the binary: usage + exit(1)
+    assert rc == 1 and "Usage: ./Multigrid [OPTIONS]" in out
+    rc, out = run_cli(exe, ["-n", "abc"], tmp_path)
+    assert rc == 1 and "Error: Please, insert a number after -n" in out
+
+
+def test_cli_rejects_a_negative_maxit(tmp_path):
+    exe = mgbuild.build_cli()
+    rc, out = run_cli(exe, ["-n", "33", "-ml", "3", "-maxit", "-5"], tmp_path)
+    assert rc == 1 and "Error: Please, insert a valid -maxit value" in out
+
+
+def test_mirror_matrix_accessors_match_the_reference_semantics(tmp_path):
+    """PoissonMatrix::nonZerosInRow / Domain::inRowConnections / Utils::saveMatrixOnFile
+    (linear_system.hpp:44-46, domain.cpp:26-34, utilities.hpp:27-41): host-only, no GPU needed."""
+    src = tmp_path / "m.cpp"
+    src.write_text('''#include "allIncludes.hpp"
+int main() {
+    MultiGrid::SquareDomain d(5, 4.0, 0), d1(5, 4.0, 1);
+    MultiGrid::PoissonMatrix<double> A(d, 2.0), A1(d1, 2.0);
+    if (A.nonZerosInRow(0).size() != 1 || A.nonZerosInRow(0)[0] != 0) return 1;          // Dirichlet row: {l}
+    const std::vector<size_t> r = A.nonZerosInRow(6);                                        // interior (1,1)
+    if (r != std::vector<size_t>{1, 5, 6, 7, 11}) return 2;
+    if (A1.nonZerosInRow(4) != std::vector<size_t>{1, 3, 4, 5, 7}) return 3;                 // level 1: width 3, centre node
+    if (A.coeffRef(6, 6) != 4. * 2.0 / 1.0 || A.coeffRef(6, 7) != -2.0 / 1.0 || A.coeffRef(0, 0) != 1.) return 4;
+    if (A1.coeffRef(4, 4) != 4. * 2.0 / 4.0 || A1.coeffRef(4, 1) != -2.0 / 4.0) return 5;   // h doubles per level
+    Utils::saveMatrixOnFile(A, "A.txt");
+    return 0;
+}
+''')
+    exe = tmp_path / "m"
+    subprocess.run(["g++", "-std=c++20", "-O1", "-I" + os.path.join(ROOT, "tests", "cpp", "shim"),
+                    "-I" + os.path.join(ROOT, "include"), "-I" + mgbuild.HOST, str(src),
+                    os.path.join(mgbuild.HOST, "utilities.cpp"), "-L" + mgbuild.LIB_DIR, "-lmg_hip",
+                    "-Wl,-rpath," + mgbuild.LIB_DIR, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    mgbuild.build()
+    p = subprocess.run([str(exe)], cwd=tmp_path)
+    assert p.returncode == 0
+    lines = open(tmp_path / "A.txt").read().split("\n")
+    assert lines[0] == "25 25 61"            # rows cols nonZeros (25 + 4 * 9 interior connections)
+    assert lines[1] == "0 0 1" and "6 6 8" in lines and "6 7 -2" in lines
+    assert len([l for l in lines if l]) == 1 + 16 + 9 * 5   # 16 boundary rows of 1 entry, 9 interior rows of 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,key", [("-n 65 -a 2.5 -w 4 -ml 4 -test 1 -smt 1", "n65_a2.5_w4_ml4_t1_s1"),
+                                      ("-n 33 -a 1 -w 10 -ml 3 -test 1 -smt 0", "n33_a1_w10_ml3_t1_s0"),
+                                      ("-n 257 -a 1 -w 10 -ml 3 -test 1 -smt 1", "n257_a1_w10_ml3_t1_s1"),
+                                      ("-n 385 -a 1 -w 10 -ml 5 -test 0 -smt 2", "n385_a1_w10_ml5_t0_s2")])
+def test_reference_main_cpp_on_the_mirror_reproduces_the_reference_runs(args, key, tmp_path):
+    """The reference's unmodified main() (built in the container by __graft_entry__.build() from the
+    file where it lies; the binary travels, the source does not) driving the HIP kernels through the
+    mirror classes: same stdout protocol and the reference's own history -- incl. BASELINE config 1 and
+    the `-smt 2` (BiCGSTAB -> Jacobi cycle) fixture run."""
+    exe = mgbuild.build_reference_main()
+    if not exe:
+        pytest.skip("tests/cpp/_build/refmain_mirror was not built (needs /root/reference at build time)")
+    rc, out = run_cli(exe, args.split(), tmp_path)
+    assert rc == 0, out
+    case = [c for c in json.load(open(os.path.join(G, "ref_solve.json"))) if c["key"] == key][0]
+    ref = np.array([float(x) for x in case["hist"]])
+    hist = [float(x) for x in open(tmp_path / "MGGS4.txt").read().split()]
+    assert abs(int(hist[0]) - len(ref)) <= 1
+    m = min(len(hist) - 1, len(ref))
+    np.testing.assert_allclose(hist[1:1 + m], ref[:m], rtol=2e-3)
+    np.testing.assert_allclose(hist[1:5], ref[:4], rtol=1e-5)     # the file holds 6 significant digits
+    assert ("BiCGSTAB iters" if key.endswith("s2") else ("Jacobi iters" if key.endswith("s1") else "GS iters")) in out
+    assert "||Solving elapsed time: " in out and "Tol: 1e-11<br>" in out and "Max iter: 1000<br>" in out
+    assert out.count("Achieved residual on coarse grid: ") == int(hist[0]) - 1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fix,args", [("web", "-n 145 -a 1 -w 10 -ml 5 -test 1 -smt 1"),
                                       ("gmgtest", "-n 385 -a 1 -w 10 -ml 5 -test 0 -smt 2")])
