@@ -119,6 +119,15 @@ int mg_cycle_async(mg_handle h, int count);
 int mg_solve(mg_handle h, double tol, int maxit, double *hist, int hist_cap, int *n_hist,
              mg_cycle_stats *per_cycle);
 
+/* Lock-step parity mode: mg_solve with the coarse Solver's stopping test taken out of the
+ * comparison. Solver::Solve (solvers.hpp:324-342) stops on `Norm() > 0.1`, so a last-bit difference in a
+ * sum of squares can move the stop by one sweep and everything after it in the 3rd-4th digit. Here the
+ * coarse solve of outer iteration i spends exactly coarse_counts[i] sweeps -- the counts a reference run
+ * spent (tests/golden/ref_solve.json) -- so that every kernel of the solve can be held to the
+ * reference's numbers tightly. Iterations beyond n_counts run free, like mg_solve. */
+int mg_solve_lockstep(mg_handle h, double tol, int maxit, const int *coarse_counts, int n_counts,
+                      double *hist, int hist_cap, int *n_hist, mg_cycle_stats *per_cycle);
+
 /* Debug stage dumps of the sawtooth cycle -- the reference's CREATE_GIF twin
  * (multigrid.hpp:160-316) writes `sol + err` sampled on the level being worked on after every
  * stage: before and after the coarse solve, after each interpolation, after each level's

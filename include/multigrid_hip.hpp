@@ -29,6 +29,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <typeinfo>
 #include <vector>
 
 #include "mg_hip.h"
@@ -273,10 +274,13 @@ private:
 }  // namespace detail
 
 // solvers.hpp:24-49 (lexicographic, in place) -> wavefront HIP kernel, bit-identical
+// (device_smoother(): the whole-loop shortcuts of Solver / SawtoothMGIteration apply to exactly this
+// class; a subclass that overrides apply_iteration_to_vec is iterated through its override)
 template <class Vector>
 class Gauss_Seidel_iteration : public detail::DeviceSmoother<Vector, MG_SMOOTH_GS_LEX> {
 public:
     using detail::DeviceSmoother<Vector, MG_SMOOTH_GS_LEX>::DeviceSmoother;
+    int device_smoother() const override { return typeid(*this) == typeid(Gauss_Seidel_iteration) ? MG_SMOOTH_GS_LEX : -1; }
 };
 // solvers.hpp:53-84 (the reference swaps `sol` with its `temp`; here `sol` keeps its buffer
 // and only the level's entries change -- the entries the reference guarantees)
@@ -284,6 +288,7 @@ template <class Vector>
 class Jacobi_iteration : public detail::DeviceSmoother<Vector, MG_SMOOTH_JACOBI> {
 public:
     using detail::DeviceSmoother<Vector, MG_SMOOTH_JACOBI>::DeviceSmoother;
+    int device_smoother() const override { return typeid(*this) == typeid(Jacobi_iteration) ? MG_SMOOTH_JACOBI : -1; }
 };
 
 // solvers.hpp:86-216. The reference constructs a BiCGSTAB-smoothed cycle (main.cpp:56) and never
@@ -437,33 +442,55 @@ private:
 };
 
 namespace detail {
-template <class S> struct smoother_id;
+// -1: a smoother type this header has no kernel for (e.g. a user's subclass of one of ours)
+template <class S> struct smoother_id { static constexpr int value = -1; };
 template <class V> struct smoother_id<Gauss_Seidel_iteration<V>> { static constexpr int value = MG_SMOOTH_GS_LEX; };
 template <class V> struct smoother_id<Jacobi_iteration<V>> { static constexpr int value = MG_SMOOTH_JACOBI; };
 // what the reference's driver runs when asked for the BiCGSTAB cycle (main.cpp:103-106: MG1)
 template <class V> struct smoother_id<BiCGSTAB<V>> { static constexpr int value = MG_SMOOTH_JACOBI; };
 }  // namespace detail
 
-// multigrid.hpp:88-158. The whole cycle (residual, injection, persistent coarse solve,
-// prolongation + nu sweeps per level, correction) runs stream-ordered on the GPU.
+// multigrid.hpp:88-158. With one of this header's smoothers the whole cycle (residual, injection,
+// persistent coarse solve, prolongation + nu sweeps per level, correction) runs stream-ordered on the
+// GPU in one mg_cycle call. Any other Smoother type (constructible from (PoissonMatrix<double>&,
+// std::vector<double>&) like the reference asks, multigrid.hpp:112-114) is honoured operator by
+// operator: its apply_iteration_to_vec is what smooths, everything around it is the mirror's device
+// operators -- the compatibility path, one PCIe round trip per application.
 template <class Vector, class Smoother>
 class SawtoothMGIteration {
+    static constexpr int kSmoother = detail::smoother_id<Smoother>::value;
+#ifdef CREATE_GIF
+    // the reference's instrumented twin (multigrid.hpp:160-316): nu = 2, coarse tolerance 0.6,
+    // and ./output/<frame>.mtx after every stage (read by test/gifMaker.py; device path only)
+    static constexpr int kNu = 2;
+    static constexpr double kCoarseTol = 0.6;
+#else
+    static constexpr int kNu = 5;             // multigrid.hpp:105
+    static constexpr double kCoarseTol = 1e-1;  // multigrid.hpp:123
+#endif
+
 public:
     SawtoothMGIteration(std::vector<PoissonMatrix<double>> &matrices, Vector &knownVec)
         : A_level(matrices), b(knownVec)
     {
         Domain &d = A_level.front().domain();
+        H = std::make_unique<detail::Hierarchy>(d.fineSize(), d.length(), A_level.front().alpha(),
+                                                static_cast<int>(A_level.size()),
+                                                kSmoother >= 0 ? kSmoother : MG_SMOOTH_JACOBI, kNu, kCoarseTol);
+        if constexpr (kSmoother >= 0) {
 #ifdef CREATE_GIF
-        // the reference's instrumented twin (multigrid.hpp:160-316): nu = 2, coarse tolerance 0.6,
-        // and ./output/<frame>.mtx after every stage (read by test/gifMaker.py)
-        H = std::make_unique<detail::Hierarchy>(d.fineSize(), d.length(), A_level.front().alpha(),
-                                                static_cast<int>(A_level.size()), detail::smoother_id<Smoother>::value,
-                                                2, 0.6);
-        mg_check(mg_set_stage_callback(H->get(), &SawtoothMGIteration::save_frame, nullptr));
-#else
-        H = std::make_unique<detail::Hierarchy>(d.fineSize(), d.length(), A_level.front().alpha(),
-                                                static_cast<int>(A_level.size()), detail::smoother_id<Smoother>::value);
+            mg_check(mg_set_stage_callback(H->get(), &SawtoothMGIteration::save_frame, nullptr));
 #endif
+        } else {
+            const size_t L = A_level.size();
+            work_res.assign(b.size(), 0.);
+            work_err.assign(b.size(), 0.);
+            for (auto &A : A_level) level_smoother.push_back(std::make_unique<Smoother>(A, work_res));
+            for (size_t l = 0; l + 1 < L; l++) to_finer.push_back(std::make_unique<InterpolationClass>(A_level[l + 1], A_level[l]));
+            fine_residual = std::make_unique<Residual<Vector>>(A_level.front(), b, work_res);
+            coarse_residual = std::make_unique<Residual<std::vector<double>>>(A_level.back(), work_res);
+            coarse_solver = std::make_unique<Solver<std::vector<double>>>(*level_smoother.back(), *coarse_residual, 2000, kCoarseTol, 1);
+        }
     }
 #ifdef CREATE_GIF
     static void save_frame(void *, int stage, int, int n, int nz, const void *values)
@@ -477,13 +504,30 @@ public:
 #endif
     void apply_iteration_to_vec(std::vector<double> &sol)
     {
-        H->upload(MG_ARR_RHS, 0, b);
-        H->upload(MG_ARR_U, 0, sol);
-        mg_cycle_stats st{};
-        mg_check(mg_cycle(H->get(), &st));
-        std::cout << "Achieved residual on coarse grid: " << st.coarse_relres << std::endl;  // multigrid.hpp:131
-        last = st;
-        H->download(MG_ARR_U, 0, sol);
+        if constexpr (kSmoother >= 0) {
+            H->upload(MG_ARR_RHS, 0, b);
+            H->upload(MG_ARR_U, 0, sol);
+            mg_cycle_stats st{};
+            mg_check(mg_cycle(H->get(), &st));
+            std::cout << "Achieved residual on coarse grid: " << st.coarse_relres << std::endl;  // multigrid.hpp:131
+            last = st;
+            H->download(MG_ARR_U, 0, sol);
+        } else {
+            sol * (*fine_residual);                                        // :127
+            coarse_residual->refresh_normalization_constant();             // :128
+            work_err * (*coarse_solver) * (*coarse_residual);              // :130
+            std::cout << "Achieved residual on coarse grid: " << coarse_residual->Norm() << std::endl;
+            last = mg_cycle_stats{coarse_solver->Iterations(), coarse_solver->Status(), coarse_residual->Norm(), 0.};
+            for (size_t l = A_level.size() - 1; l-- > 0;) {                // :134-139
+                work_err * (*to_finer[l]);
+                for (int s = 0; s < kNu; s++) work_err * (*level_smoother[l]);
+            }
+            H->upload(MG_ARR_U, 0, sol);                                   // :141-144 on the device
+            H->upload(MG_ARR_E, 0, work_err);
+            mg_check(mg_correct(H->get(), MG_ARR_U, MG_ARR_E));
+            H->download(MG_ARR_U, 0, sol);
+            H->download(MG_ARR_E, 0, work_err);
+        }
     }
     friend std::vector<double> &operator*(std::vector<double> &x_k, SawtoothMGIteration &B)
     {
@@ -497,6 +541,13 @@ private:
     Vector &b;
     std::unique_ptr<detail::Hierarchy> H;
     mg_cycle_stats last{};
+    // operator-by-operator path only
+    std::vector<double> work_res, work_err;
+    std::vector<std::unique_ptr<SmootherClass<std::vector<double>>>> level_smoother;
+    std::vector<std::unique_ptr<InterpolationClass>> to_finer;
+    std::unique_ptr<Residual<Vector>> fine_residual;
+    std::unique_ptr<Residual<std::vector<double>>> coarse_residual;
+    std::unique_ptr<Solver<std::vector<double>>> coarse_solver;
 };
 
 // ---------------------------------------------------------------------------------------

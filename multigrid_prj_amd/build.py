@@ -36,16 +36,42 @@ def is_stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """One object per source (only the stale ones are recompiled, in parallel), then one link."""
     if not force and not is_stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, "-I" + os.path.join(ROOT, "include"), *srcs, "-o", LIB_PATH + ".tmp"]
-    if os.environ.get("MG_WITH_RCCL", "1") == "1" and os.path.exists("/opt/rocm/lib/librccl.so"):
-        cmd += ["-DMG_WITH_RCCL=1", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    flags = [f for f in FLAGS if f != "-shared"] + ["-I" + os.path.join(ROOT, "include")]
+    with_rccl = os.environ.get("MG_WITH_RCCL", "1") == "1" and os.path.exists("/opt/rocm/lib/librccl.so")
+    if with_rccl:
+        flags.append("-DMG_WITH_RCCL=1")
+    hdr_time = max(os.path.getmtime(f) for f in _inputs() if f.endswith((".h", ".hpp")))
+    srcs = [f for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    jobs = []
+    for f in srcs:
+        src, obj = os.path.join(CSRC, f), os.path.join(obj_dir, f + (".rccl" if with_rccl else "") + ".o")
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)
+        jobs.append((src, obj, stale))
+
+    def compile_one(job):
+        src, obj, stale = job
+        if stale:
+            cmd = [hipcc, *flags, "-c", src, "-o", obj + ".tmp"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        objs = list(ex.map(compile_one, jobs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
+    if with_rccl:
+        cmd += ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH

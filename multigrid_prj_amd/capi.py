@@ -86,7 +86,7 @@ EXPORTS = [
     "mg_last_error", "mg_device_count", "mg_create", "mg_destroy", "mg_level_n", "mg_level_nz",
     "mg_level_coefficients", "mg_set_rhs", "mg_set_solution", "mg_get_solution", "mg_set_array",
     "mg_get_array", "mg_zero_array", "mg_smooth", "mg_residual", "mg_sumsq", "mg_restrict",
-    "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_coarse_solve_ex", "mg_cycle", "mg_cycle_async", "mg_solve",
+    "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_coarse_solve_ex", "mg_cycle", "mg_cycle_async", "mg_solve", "mg_solve_lockstep",
     "mg_set_stage_callback", "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_profile_fused", "mg_device_bytes", "mg_comm_unique_id", "mg_comm_selftest",
     "mg_create_distributed", "mg_create_distributed_hostcomm", "mg_plan_slab",
 ]
@@ -130,6 +130,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.mg_cycle.argtypes = [vp, C.POINTER(MgCycleStats)]
     L.mg_cycle_async.argtypes = [vp, i]
     L.mg_solve.argtypes = [vp, C.c_double, i, dp, i, C.POINTER(i), C.POINTER(MgCycleStats)]
+    L.mg_solve_lockstep.argtypes = [vp, C.c_double, i, C.POINTER(i), i, dp, i, C.POINTER(i), C.POINTER(MgCycleStats)]
     L.mg_set_stage_callback.argtypes = [vp, STAGE_FN, vp]
     L.mg_sync.argtypes = [vp]
     L.mg_timer_start.argtypes = [vp]
@@ -284,6 +285,14 @@ class Solver:
         hist = (C.c_double * (maxit + 1))(); nh = C.c_int(0)
         stats = (MgCycleStats * max(maxit, 1))()
         _check(self.lib.mg_solve(self.h, tol, maxit, hist, maxit + 1, C.byref(nh), stats))
+        return np.array(hist[:nh.value]), list(stats[:nh.value - 1])
+
+    def solve_lockstep(self, coarse_counts, tol=1e-11, maxit=1000):
+        """mg_solve with outer iteration i's coarse solve spending exactly coarse_counts[i] sweeps"""
+        hist = (C.c_double * (maxit + 1))(); nh = C.c_int(0)
+        stats = (MgCycleStats * max(maxit, 1))()
+        cnt = (C.c_int * max(len(coarse_counts), 1))(*[int(c) for c in coarse_counts])
+        _check(self.lib.mg_solve_lockstep(self.h, tol, maxit, cnt, len(coarse_counts), hist, maxit + 1, C.byref(nh), stats))
         return np.array(hist[:nh.value]), list(stats[:nh.value - 1])
 
     def set_stage_callback(self, fn):

@@ -155,6 +155,15 @@ int mg_solve(mg_handle h, double tol, int maxit, double *hist, int hist_cap, int
     if (maxit < 0) return bad("mg_solve: negative maxit");
     return guarded([&] { return h->impl->solve(tol, maxit, hist, hist_cap, n_hist, per_cycle); });
 }
+int mg_solve_lockstep(mg_handle h, double tol, int maxit, const int *coarse_counts, int n_counts,
+                      double *hist, int hist_cap, int *n_hist, mg_cycle_stats *per_cycle)
+{
+    MG_H(h);
+    if (maxit < 0 || n_counts < 0 || (n_counts > 0 && !coarse_counts)) return bad("mg_solve_lockstep: bad argument");
+    for (int i = 0; i < n_counts; i++)
+        if (coarse_counts[i] < 0) return bad("mg_solve_lockstep: negative sweep count");
+    return guarded([&] { return h->impl->solve(tol, maxit, hist, hist_cap, n_hist, per_cycle, coarse_counts, n_counts); });
+}
 int mg_set_stage_callback(mg_handle h, mg_stage_fn fn, void *user)
 {
     MG_H(h);

@@ -892,6 +892,7 @@ int Solver::coarse_t(int level, int ax, int ar)
 {
     // the coarsest-grid solver of a zebra hierarchy smooths with red-black Gauss-Seidel (mg_desc.h)
     const int sm = d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother;
+    if (lock_iters_ >= 0) return coarse_ex_t<T>(level, ax, ar, sm, lock_iters_, d_.coarse_tol, 1);
     return coarse_ex_t<T>(level, ax, ar, sm, d_.coarse_maxit, d_.coarse_tol,
                           d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0);
 }
@@ -937,8 +938,8 @@ int Solver::coarse_full_t()
     MG_HIP(hipMemsetAsync(full_[1], 0, (size_t)(gfull_.nz + 2) * (size_t)gfull_.plane * esize(), stream_));
     launch_coarse_solve<T>(stream_, gfull_, coef_of<T>(L), (T)d_.omega,
                            d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother, fullptr<T>(1), fullptr<T>(2),
-                           fullptr<T>(0), d_.coarse_maxit, d_.coarse_tol, d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0,
-                           d_coarse_);
+                           fullptr<T>(0), lock_iters_ >= 0 ? lock_iters_ : d_.coarse_maxit, d_.coarse_tol,
+                           (lock_iters_ >= 0 || d_.coarse_mode == MG_COARSE_FIXED) ? 1 : 0, d_coarse_);
     MG_HIP(hipGetLastError());
     return MG_OK;
 }
@@ -1097,7 +1098,7 @@ int Solver::cycle_async(int count)
 
 // Outer loop of src/main.cpp:72-116.
 int Solver::solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist,
-                  mg_cycle_stats *per_cycle)
+                  mg_cycle_stats *per_cycle, const int *lock_counts, int n_lock)
 {
     MG_HIP(hipSetDevice(device_));
     double nb = 0, nr = 0;
@@ -1109,7 +1110,10 @@ int Solver::solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist
     for (int it = 0; it < maxit; it++) {
         if (d_.outer_pre_gs > 0)                             // `u * GS * GS` main.cpp:85
             MG_TRY(smooth(0, MG_SMOOTH_GS_LEX, d_.outer_pre_gs, MG_ARR_U, MG_ARR_RHS));
-        MG_TRY(cycle(per_cycle ? &per_cycle[it] : nullptr));  // `* MGx`
+        lock_iters_ = (lock_counts && it < n_lock) ? lock_counts[it] : -1;
+        const int crc = cycle(per_cycle ? &per_cycle[it] : nullptr);  // `* MGx`
+        lock_iters_ = -1;
+        MG_TRY(crc);
         MG_TRY(residual(0, MG_ARR_U, MG_ARR_RHS, -1, &nr));  // main.cpp:86
         double rel = std::sqrt(nr / nb);
         if (hist && nh < hist_cap) hist[nh] = rel;

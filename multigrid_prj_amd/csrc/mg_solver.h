@@ -67,8 +67,10 @@ public:
                         mg_cycle_stats *st);
     int cycle(mg_cycle_stats *st);
     int cycle_async(int count);
+    // lock_counts != nullptr: outer iteration i < n_lock runs its coarse solve for exactly
+    // lock_counts[i] sweeps (mg_solve_lockstep)
     int solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist,
-              mg_cycle_stats *per_cycle);
+              mg_cycle_stats *per_cycle, const int *lock_counts = nullptr, int n_lock = 0);
     int set_stage_callback(mg_stage_fn fn, void *user);
     int sync();
     int timer_start();
@@ -142,6 +144,7 @@ private:
     void *h_stage_ = nullptr;      // pinned staging buffer of set_array / get_array
     size_t h_stage_bytes_ = 0;
     bool overlap_ = true;  // MG_OVERLAP=0 disables (debugging)
+    int lock_iters_ = -1;  // >= 0: the next coarse solve runs exactly this many sweeps (lock-step parity mode)
     Geom gfull_{};
     void *full_[3] = {nullptr, nullptr, nullptr};
     std::vector<SlabPlan> planT_;

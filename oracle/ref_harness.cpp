@@ -10,7 +10,7 @@
 // operator by operator and cycle by cycle at full double precision.
 //
 // usage: ref_ops <op> <n> <levels> <level> <alpha> <length> <smt> <test> <in.bin> <out.bin>
-//   in.bin : u[n*n] then b[n*n]            (ignored by op=solve_full)
+//   in.bin : u[n*n] then b[n*n]            (ignored by op=solve_full / solve_counts)
 //   out.bin: op-specific doubles, see each branch
 #include "allIncludes.hpp"
 
@@ -28,6 +28,18 @@ struct CountingSmoother : public SmootherClass<Vec> {
     long count = 0;
     explicit CountingSmoother(SmootherClass<Vec> &s) : inner(s) {}
     void apply_iteration_to_vec(Vec &sol) override { inner.apply_iteration_to_vec(sol); ++count; }
+};
+
+// The same idea for a whole cycle: SawtoothMGIteration builds its smoothers itself from the template
+// argument (multigrid.hpp:112-114), so a subclass that counts its applications per level width shows
+// how many sweeps the cycle's coarse Solver spent (the coarsest level's smoother is applied by nobody
+// else: the nu post-sweeps run on levels L-2 .. 0, multigrid.hpp:134-139).
+static std::vector<long> g_applied(1 << 16, 0);
+template <class Base>
+struct Counted : public Base {
+    size_t width;
+    Counted(PoissonMatrix<double> &A, Vec &f) : Base(A, f), width(A.getWidth()) {}
+    void apply_iteration_to_vec(Vec &sol) override { g_applied[width]++; Base::apply_iteration_to_vec(sol); }
 };
 
 static Vec read_doubles(FILE *f, size_t cnt)
@@ -94,6 +106,39 @@ int main(int argc, char **argv)
         Vec bvec(n * n);
         for (size_t i = 0; i < n * n; i++) bvec[i] = fvec[i];
         write_doubles(fout, bvec);
+        std::fclose(fout);
+        return 0;
+    }
+
+    if (op == "solve_counts") {
+        // the same outer loop with counting smoothers: hist again + coarse sweeps per cycle
+        std::function<double(const double, const double)> f, g;
+        Utils::init_test_functions(f, g, test);
+        DataVector<double> fvec(domains.front(), f, g);
+        Vec u(n * n, 0.), res(n * n, 0.), hist, counts;
+        SawtoothMGIteration<DataVector<double>, Counted<Gauss_Seidel_iteration<Vec>>> MG0(A, fvec);
+        SawtoothMGIteration<DataVector<double>, Counted<Jacobi_iteration<Vec>>> MG1(A, fvec);
+        Residual<DataVector<double>> RES(A.front(), fvec, res);
+        Gauss_Seidel_iteration<DataVector<double>> GS(A.front(), fvec);
+        std::stringstream captured;
+        std::streambuf *old = std::cout.rdbuf(captured.rdbuf());
+        const size_t wc = A.back().getWidth();
+        u * RES;
+        hist.push_back(RES.Norm());
+        for (int i = 0; i < 1000; i++) {
+            const long before = g_applied[wc];
+            if (smt == 0) u * GS * GS * MG0; else u * GS * GS * MG1;
+            long spent = g_applied[wc] - before;
+            counts.push_back((double)spent);
+            u * RES;
+            hist.push_back(RES.Norm());
+            if (hist.back() <= TOL) break;
+        }
+        std::cout.rdbuf(old);
+        write_double(fout, (double)hist.size());
+        write_doubles(fout, hist);
+        write_doubles(fout, counts);
+        write_doubles(fout, u);
         std::fclose(fout);
         return 0;
     }

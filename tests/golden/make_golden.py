@@ -8,8 +8,9 @@ What it writes (data only -- inputs and expected outputs, never reference source
                    (Jacobi, Gauss-Seidel, Residual, interpolate, Solver::Solve, one
                    SawtoothMGIteration) obtained through oracle/_ref/ref_ops
   ref_solve.json   residual histories (17 s.d.), per-cycle coarse residuals (6 s.d.,
-                   parsed from the reference's own stdout) for whole solves
-  ref_solve_u.npz  final solution vectors of the small whole solves
+                   parsed from the reference's own stdout) and per-cycle coarse sweep counts
+                   (counting subclasses of the reference smoothers) for whole solves
+  ref_solve_u.npz  final solution vectors of the small whole solves and of BASELINE config 1 (n = 257)
   fixture_*.txt/.npz   the reference's own result files, copied as data:
                    GeometricMultigrid/test/{MGGS4.txt,x.mtx} (-n 385 -a 1 -w 10 -ml 5 -test 0 -smt 2)
                    WebInterface/{MGGS4.txt,x.mtx}            (-n 145 -a 1 -w 10 -ml 5 -test 1 -smt 1)
@@ -91,10 +92,17 @@ def main():
         coarse = o[1 + nh:1 + nh + (nh - 1)]
         u = o[1 + nh + (nh - 1):1 + nh + (nh - 1) + n * n]
         key = f"n{n}_a{a}_w{w}_ml{ml}_t{test}_s{smt}"
+        # the same run with counting smoothers (ref_harness.cpp: Counted<>): sweeps the coarse Solver
+        # spent in every cycle -- what mg_solve_lockstep replays -- and the same history again
+        oc = run_op("solve_counts", n, ml, 0, float(a), float(w), smt, test)
+        assert int(oc[0]) == nh and np.array_equal(oc[1:1 + nh], hist), key
+        counts = oc[1 + nh:1 + nh + (nh - 1)]
+        assert np.array_equal(oc[1 + nh + (nh - 1):1 + nh + (nh - 1) + n * n], u), key
         solves.append(dict(key=key, n=n, alpha=a, length=w, levels=ml, test=test, smt=smt,
                            hist=[repr(float(x)) for x in hist],
-                           coarse_relres=[repr(float(x)) for x in coarse]))
-        if n <= 65:
+                           coarse_relres=[repr(float(x)) for x in coarse],
+                           coarse_counts=[int(c) for c in counts]))
+        if n <= 65 or n == 257:   # 257: BASELINE config 1, the final solution vector north_star asks for
             us[key] = u.reshape(n, n)
         print(key, nh, hist[-1])
     with open(os.path.join(HERE, "ref_solve.json"), "w") as f:

@@ -14,9 +14,12 @@ from oracle import pyoracle as po
 
 class SlabVCycle:
     def __init__(self, desc, rank, world, dist):
-        assert desc.dim == 3 and desc.dtype == capi.MG_F64 and desc.cycle == capi.CYCLE_V
+        assert desc.dim == 3 and desc.cycle == capi.CYCLE_V
         assert desc.smoother == capi.SMOOTH_JACOBI and desc.coarse_mode == capi.COARSE_FIXED
         self.d, self.rank, self.world, self.dist = desc, rank, world, dist
+        # fp32 (BASELINE config 4): float32 arrays; python-float coefficients are weak scalars in numpy 2,
+        # i.e. they are rounded to float32 first and every operation rounds to float32 -- the oracle's (REAL) casts
+        self.np = np.float64 if desc.dtype == capi.MG_F64 else np.float32
         self.od = po.make_desc(**{f: getattr(desc, f) for f, _ in po.MgDesc._fields_ if f != "aniso"})
         self.ops = po.Ops(self.od)
         self.L = desc.levels
@@ -29,11 +32,11 @@ class SlabVCycle:
         for l in range(self.L):
             if l <= self.T:
                 z0, nz, _ = self.plan[l][rank]
-                self.u[l] = np.zeros((nz + 2, self.n[l], self.n[l]))
-                self.rhs[l] = np.zeros((nz, self.n[l], self.n[l]))
+                self.u[l] = np.zeros((nz + 2, self.n[l], self.n[l]), self.np)
+                self.rhs[l] = np.zeros((nz, self.n[l], self.n[l]), self.np)
             elif rank == 0:
-                self.u[l] = np.zeros((self.n[l],) * 3)
-                self.rhs[l] = np.zeros((self.n[l],) * 3)
+                self.u[l] = np.zeros((self.n[l],) * 3, self.np)
+                self.rhs[l] = np.zeros((self.n[l],) * 3, self.np)
 
     # ---- communication -------------------------------------------------------------
     def exchange(self, a):
@@ -56,12 +59,12 @@ class SlabVCycle:
         """owned planes (nz,n,n) of level l -> full array on rank 0"""
         import torch
         if self.rank == 0:
-            full = np.zeros((self.n[l],) * 3)
+            full = np.zeros((self.n[l],) * 3, self.np)
             z0, nz, _ = self.plan[l][0]
             full[z0:z0 + nz] = slab
             for r in range(1, self.world):
                 z0, nz, _ = self.plan[l][r]
-                t = torch.empty((nz, self.n[l], self.n[l]), dtype=torch.float64)
+                t = torch.empty((nz, self.n[l], self.n[l]), dtype=torch.float64 if self.np == np.float64 else torch.float32)
                 self.dist.recv(t, r)
                 full[z0:z0 + nz] = t.numpy()
             return full
@@ -76,7 +79,7 @@ class SlabVCycle:
                 zr, nr, _ = self.plan[l][r]
                 self.dist.send(torch.from_numpy(np.ascontiguousarray(full[zr:zr + nr])), r)
             return full[z0:z0 + nz].copy()
-        t = torch.empty((nz, self.n[l], self.n[l]), dtype=torch.float64)
+        t = torch.empty((nz, self.n[l], self.n[l]), dtype=torch.float64 if self.np == np.float64 else torch.float32)
         self.dist.recv(t, 0)
         return t.numpy()
 
@@ -130,7 +133,7 @@ class SlabVCycle:
         n, nc = self.n[l], self.n[l + 1]
         z0f, nzf, _ = self.plan[l][self.rank]
         z0c, nzc, _ = self.plan[l + 1][self.rank]
-        ext = np.zeros((nzf + 2, n, n)); ext[1:-1] = r_slab
+        ext = np.zeros((nzf + 2, n, n), self.np); ext[1:-1] = r_slab
         if self.d.restriction == capi.RESTRICT_FULLW:
             self.exchange(ext)
         K = np.arange(z0c, z0c + nzc)
@@ -162,16 +165,16 @@ class SlabVCycle:
         z0c, _, _ = self.plan[l + 1][self.rank]
         c = self.u[l + 1]
         gz = np.arange(z0f, z0f + nzf)
-        vz = np.empty((nzf, c.shape[1], c.shape[2]))
+        vz = np.empty((nzf, c.shape[1], c.shape[2]), self.np)
         ev = gz % 2 == 0
         vz[ev] = c[gz[ev] // 2 - z0c + 1]
         od = ~ev
         k0 = (gz[od] - 1) // 2 - z0c + 1
         vz[od] = 0.5 * (c[k0] + c[k0 + 1])
-        vy = np.empty((nzf, n, c.shape[2]))
+        vy = np.empty((nzf, n, c.shape[2]), self.np)
         vy[:, ::2] = vz
         vy[:, 1::2] = 0.5 * (vz[:, :-1] + vz[:, 1:])
-        vx = np.empty((nzf, n, n))
+        vx = np.empty((nzf, n, n), self.np)
         vx[:, :, ::2] = vy
         vx[:, :, 1::2] = 0.5 * (vy[:, :, :-1] + vy[:, :, 1:])
         return vx
@@ -235,9 +238,9 @@ class SlabVCycle:
         return self.u[0][1:-1].copy()
 
     def solve_hist(self, k):
-        nb = self.allreduce(float((self.rhs[0] ** 2).sum()))
-        hist = [np.sqrt(self.allreduce(float((self.residual(0) ** 2).sum())) / nb)]
+        nb = self.allreduce(float((self.rhs[0].astype(np.float64) ** 2).sum()))
+        hist = [np.sqrt(self.allreduce(float((self.residual(0).astype(np.float64) ** 2).sum())) / nb)]
         for _ in range(k):
             self.cycle()
-            hist.append(np.sqrt(self.allreduce(float((self.residual(0) ** 2).sum())) / nb))
+            hist.append(np.sqrt(self.allreduce(float((self.residual(0).astype(np.float64) ** 2).sum())) / nb))
         return hist

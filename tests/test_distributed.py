@@ -52,8 +52,8 @@ def _run_ranks(mode, world, case, tmp_path, timeout=600):
     return np.concatenate([p["u"] for p in parts], axis=0), [p["hist"] for p in parts], int(parts[0]["fg"])
 
 
-def _case(tmp_path, n, levels, restriction, cycles=2, semi=0, zebra=False, rb=False):
-    desc = dict(dim=3, n=n, levels=levels, dtype=0, length=1.0, alpha=1.0, cycle=1, smoother=1, omega=6 / 7,
+def _case(tmp_path, n, levels, restriction, cycles=2, semi=0, zebra=False, rb=False, dtype=0):
+    desc = dict(dim=3, n=n, levels=levels, dtype=dtype, length=1.0, alpha=1.0, cycle=1, smoother=1, omega=6 / 7,
                 nu_pre=2, nu_post=2, restriction=restriction, coarse_mode=1, coarse_maxit=20, outer_pre_gs=0,
                 dist_min_n=33)
     if semi:  # eps = 0.25 -> one semi-coarsening (log4(1/eps) = 1), then standard coarsening
@@ -63,6 +63,8 @@ def _case(tmp_path, n, levels, restriction, cycles=2, semi=0, zebra=False, rb=Fa
     if zebra:  # strong y-coupling, zebra lines along y (they never cross the z-slabs)
         desc.update(smoother=3, omega=1.0, aniso=(1.0, 50.0, 1.0))
     b = po.fill_rhs_3d(n, 1.0, 1.0, 1)
+    if dtype == 1:
+        b = b.astype(np.float32)
     rhs = os.path.join(tmp_path, "rhs.npy")
     np.save(rhs, b)
     return dict(desc=desc, rhs=rhs, cycles=cycles), desc, b
@@ -77,26 +79,31 @@ def _oracle(desc, b, cycles):
     return o.get_solution(), hist
 
 
-@pytest.mark.parametrize("world,n,levels,restriction,expect_fg", [
-    (2, 65, 3, 1, 2),    # two distributed levels, 17^3 gathered on rank 0, full weighting
-    (2, 65, 4, 0, 2),    # injection, two gathered levels
-    (3, 129, 3, 1, 3),   # every level distributed: the coarse solve itself is gathered
+@pytest.mark.parametrize("world,n,levels,restriction,expect_fg,dtype", [
+    (2, 65, 3, 1, 2, 0),    # two distributed levels, 17^3 gathered on rank 0, full weighting
+    (2, 65, 4, 0, 2, 0),    # injection, two gathered levels
+    (3, 129, 3, 1, 3, 0),   # every level distributed: the coarse solve itself is gathered
+    (2, 65, 3, 1, 2, 1),    # fp32 (BASELINE config 4's precision)
+    (3, 65, 4, 1, 2, 1),    # fp32, three ranks
 ])
-def test_slab_decomposition_model_gloo(world, n, levels, restriction, expect_fg, tmp_path):
-    case, desc, b = _case(tmp_path, n, levels, restriction)
+def test_slab_decomposition_model_gloo(world, n, levels, restriction, expect_fg, dtype, tmp_path):
+    case, desc, b = _case(tmp_path, n, levels, restriction, dtype=dtype)
     u, hists, fg = _run_ranks("model", world, case, tmp_path)
     assert fg == expect_fg
     u_ref, h_ref = _oracle(desc, b, case["cycles"])
     assert np.array_equal(u, u_ref)
     for h in hists:  # every rank sees the same all-reduced history
-        np.testing.assert_allclose(h, h_ref, rtol=1e-12)
+        np.testing.assert_allclose(h, h_ref, rtol=1e-12 if dtype == 0 else 1e-6)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,levels,restriction", [(2, 65, 3, 1), (2, 65, 4, 0), (3, 129, 3, 1), (2, 129, 4, 1), (2, 257, 4, 1)])
-def test_hip_distributed_solver_two_processes_one_gpu(world, n, levels, restriction, tmp_path):
+@pytest.mark.parametrize("world,n,levels,restriction,dtype", [
+    (2, 65, 3, 1, 0), (2, 65, 4, 0, 0), (3, 129, 3, 1, 0), (2, 129, 4, 1, 0), (2, 257, 4, 1, 0),
+    # fp32 = BASELINE config 4's precision: narrow levels, the fused pair on slabs (n >= 129: 32-float4 rows), 2 and 3 ranks
+    (2, 65, 3, 1, 1), (3, 129, 3, 1, 1), (2, 257, 4, 1, 1), (3, 257, 5, 1, 1)])
+def test_hip_distributed_solver_two_processes_one_gpu(world, n, levels, restriction, dtype, tmp_path):
     from multigrid_prj_amd import capi
-    case, desc, b = _case(tmp_path, n, levels, restriction)
+    case, desc, b = _case(tmp_path, n, levels, restriction, dtype=dtype)
     u, hists, fg = _run_ranks("hip", world, case, tmp_path)
     with capi.Solver(capi.make_desc(**desc)) as s:  # single-GPU run of the same problem
         s.set_rhs(b)
@@ -108,7 +115,7 @@ def test_hip_distributed_solver_two_processes_one_gpu(world, n, levels, restrict
     u_ref, h_ref = _oracle(desc, b, case["cycles"])
     assert np.array_equal(u, u_ref)
     for h in hists:
-        np.testing.assert_allclose(h, h1, rtol=1e-12)
+        np.testing.assert_allclose(h, h1, rtol=1e-12 if dtype == 0 else 1e-6)
 
 
 @pytest.mark.gpu

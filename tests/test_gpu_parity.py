@@ -249,6 +249,54 @@ def test_vcycle_headline_size_513_bit_exact(smoother):
         assert np.array_equal(sg.get_solution(), so.get_solution())
 
 
+@pytest.mark.parametrize("smoother", [capi.SMOOTH_JACOBI, capi.SMOOTH_RBGS])
+def test_config5_anisotropic_semi_coarsened_513_bit_exact(smoother):
+    """BASELINE config 5 at full size: -(dxx + dyy + 0.01 dzz) on 513^3, 8 levels of which the first three
+    coarsen x,y only (k = log4(1/eps) semi-coarsenings, then standard ones), V(2,2), full weighting, 20 coarse
+    sweeps: two cycles on the GPU against two cycles of the oracle, all 1.35e8 unknowns bit for bit, and the
+    cycle must converge like multigrid (standard coarsening stalls at 0.9 on this operator)."""
+    n = 513
+    kw = dict(dim=3, n=n, levels=8, dtype=capi.MG_F64, length=1.0, alpha=1.0, cycle=capi.CYCLE_V, nu_pre=2, nu_post=2,
+              smoother=smoother, omega=6 / 7 if smoother == capi.SMOOTH_JACOBI else 1.0, restriction=capi.RESTRICT_FULLW,
+              coarse_mode=capi.COARSE_FIXED, coarse_maxit=20, outer_pre_gs=0, aniso=(1.0, 1.0, 0.01), semi_xy=3)
+    sg = capi.Solver(capi.make_desc(**kw)); so = po.Solver(po.make_desc(**kw))
+    b = po.fill_rhs_3d(n, 1.0, 1.0, 1)
+    with sg:
+        assert [sg.level_shape(l) for l in (0, 3, 4, 7)] == [(513, 513, 513), (513, 65, 65), (257, 33, 33), (33, 5, 5)]
+        sg.set_rhs(b); so.set_rhs(b)
+        del b
+        for _ in range(2):
+            sg.cycle(); so.cycle()
+        assert np.array_equal(sg.get_solution(), so.get_solution())
+        hist, _ = sg.solve(0.0, 3)
+        assert hist[-1] / hist[-2] < (0.3 if smoother == capi.SMOOTH_JACOBI else 0.15), hist
+
+
+def test_config4_grid_1025_fp32_fused_operators_bit_exact():
+    """BASELINE config 4's grid (1025^3 fp32, rows of 256 four-float vectors) through every fused finest-level
+    kernel -- the sweep pair, residual + full weighting, and the pair that folds the prolongation -- as ONE
+    two-level V(2,2) cycle (the 513^3 'coarse' level is swept 4 times with the same fused pair) against the
+    oracle on the whole grid, 1.08e9 unknowns bit for bit. (8 ranks of the distributed run each hold a slab
+    of exactly this grid; k ranks == 1 rank is tests/test_distributed.py's part.)"""
+    n = 1025
+    kw = dict(dim=3, n=n, levels=2, dtype=capi.MG_F32, length=1.0, alpha=1.0, cycle=capi.CYCLE_V, nu_pre=2, nu_post=2,
+              smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW,
+              coarse_mode=capi.COARSE_FIXED, coarse_maxit=4, outer_pre_gs=0)
+    sg = capi.Solver(capi.make_desc(**kw)); so = po.Solver(po.make_desc(**kw))
+    b = po.fill_rhs_3d(n, 1.0, 1.0, 1).astype(np.float32)
+    with sg:
+        sg.set_rhs(b); so.set_rhs(b)
+        del b
+        sg.cycle(); so.cycle()
+        ug = sg.get_solution(); uo = so.get_solution()
+        assert np.array_equal(ug, uo)
+        del ug, uo
+        # the finest-level residual through the vectorised path, and its norm
+        ss = sg.residual(0, capi.ARR_U, capi.ARR_RHS, -1)
+        assert ss == pytest.approx(so.residual_fine(), rel=1e-5)
+    so.close()
+
+
 with open(os.path.join(G, "ref_solve.json")) as _f:
     SOLVES = json.load(_f)
 
@@ -270,6 +318,36 @@ def test_whole_solve_vs_reference_golden(case):
         ufile = np.load(os.path.join(G, "ref_solve_u.npz"))
         if case["key"] in ufile:
             np.testing.assert_allclose(s.get_solution(), ufile[case["key"]], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("case", SOLVES, ids=lambda c: c["key"])
+def test_whole_solve_lockstep_vs_reference_golden(case):
+    """Lock-step parity: the coarse Solver's stop test `Norm() > 0.1` is the one chaotic
+    element of the reference algorithm, so mg_solve_lockstep replays the sweep counts the REAL reference
+    spent per cycle (golden `coarse_counts`) and everything else is held tightly: the same number of
+    outer iterations, every history entry to rtol 1e-9 (norms differ from the serial loop by summation
+    order only), BASELINE config 1's final solution vector to rtol 1e-9 against the reference's and bit
+    for bit against the oracle (north_star: 'final solution vector and per-cycle residual')."""
+    smt = 1 if case["smt"] == 2 else case["smt"]
+    kw = dict(dim=2, n=case["n"], levels=case["levels"], alpha=case["alpha"], length=case["length"], smoother=smt)
+    ref = np.array([float(x) for x in case["hist"]])
+    b = po.fill_rhs_2d(case["n"], case["length"], case["test"])
+    with capi.Solver(capi.make_desc(**kw)) as s:
+        s.set_rhs(b)
+        hist, stats = s.solve_lockstep(case["coarse_counts"], 1e-11, 1000)
+        assert len(hist) == len(ref)
+        np.testing.assert_allclose(hist, ref, rtol=1e-9)
+        assert [st.coarse_iters for st in stats] == case["coarse_counts"]
+        refc = np.array([float(x) for x in case["coarse_relres"]])
+        np.testing.assert_allclose([st.coarse_relres for st in stats], refc, rtol=2e-5)  # the reference prints 6 digits
+        u = s.get_solution()
+    ufile = np.load(os.path.join(G, "ref_solve_u.npz"))
+    if case["key"] in ufile:      # every n <= 65 case and BASELINE config 1 (n = 257, both smoothers)
+        np.testing.assert_allclose(u, ufile[case["key"]], rtol=1e-9, atol=1e-12)
+    o = po.Solver(po.make_desc(**kw)); o.set_rhs(b)
+    ho, so = o.solve(1e-11, 1000)
+    assert [st.coarse_iters for st in so] == case["coarse_counts"]
+    assert np.array_equal(u, o.get_solution())
 
 
 @pytest.mark.parametrize("fix,n,test", [("web", 145, 1), ("gmgtest", 385, 0)])
@@ -422,6 +500,51 @@ def test_manufactured_solution_second_order():
             assert hist[-1] <= 1e-10
             errs.append(np.abs(s.get_solution() - po.exact_3d(n, 1.0)).max())
     assert 3.5 < errs[0] / errs[1] < 4.5
+
+
+def _manufactured(n, aniso, alpha=1.0, length=1.0):
+    """numpy only (no oracle in the loop): u* = sin(pi x) sin(pi y) sin(pi z) on the unit cube and the
+    right-hand side f = -alpha (ax dxx + ay dyy + az dzz) u* = alpha (ax+ay+az) pi^2 u*, g = 0."""
+    t = np.sin(np.pi * np.arange(n) / (n - 1))
+    t[0] = t[-1] = 0.0
+    ustar = t[:, None, None] * t[None, :, None] * t[None, None, :]
+    # array axes are (z, y, x) and aniso = (ax, ay, az); u* is symmetric in them
+    return ustar, alpha * sum(aniso) * (np.pi / length) ** 2 * ustar
+
+
+MANUFACTURED = [
+    # every extension the reference has no code for gets one oracle-independent anchor: discretisation
+    # error of the converged GPU solution against the analytic one, second order in h
+    dict(id="jacobi-omega-f64", smoother=capi.SMOOTH_JACOBI, omega=6 / 7, dtype=capi.MG_F64),
+    dict(id="jacobi-f32", smoother=capi.SMOOTH_JACOBI, omega=6 / 7, dtype=capi.MG_F32),
+    dict(id="rbgs-f32", smoother=capi.SMOOTH_RBGS, omega=1.0, dtype=capi.MG_F32),
+    dict(id="semi-aniso-jacobi", smoother=capi.SMOOTH_JACOBI, omega=0.8, dtype=capi.MG_F64, aniso=(1.0, 1.0, 0.01), semi_xy=3, levels=5),
+    dict(id="semi-aniso-rbgs", smoother=capi.SMOOTH_RBGS, omega=1.0, dtype=capi.MG_F64, aniso=(1.0, 1.0, 0.0625), semi_xy=2, levels=4),
+    dict(id="zebra-y", smoother=capi.SMOOTH_ZEBRA_Y, omega=1.0, dtype=capi.MG_F64, aniso=(1.0, 100.0, 1.0)),
+    dict(id="inject-jacobi", smoother=capi.SMOOTH_JACOBI, omega=6 / 7, dtype=capi.MG_F64, restriction=capi.RESTRICT_INJECT),
+]
+
+
+@pytest.mark.parametrize("case", MANUFACTURED, ids=lambda c: c["id"])
+def test_manufactured_solution_anchors_every_extension(case):
+    case = dict(case); case.pop("id")
+    f32 = case["dtype"] == capi.MG_F32
+    aniso = case.get("aniso", (1.0, 1.0, 1.0))
+    levels = case.pop("levels", 4)
+    errs = []
+    for n in (33, 65):
+        kw = dict(dim=3, n=n, levels=levels, length=1.0, alpha=1.0, cycle=capi.CYCLE_V, nu_pre=2, nu_post=2,
+                  coarse_mode=capi.COARSE_FIXED, coarse_maxit=60, outer_pre_gs=0,
+                  **{"restriction": capi.RESTRICT_FULLW, **case})
+        ustar, f = _manufactured(n, aniso)
+        with capi.Solver(capi.make_desc(**kw)) as s:
+            s.set_rhs(f)
+            hist, _ = s.solve(2e-6 if f32 else 1e-10, 60)
+            assert hist[-1] <= (2e-6 if f32 else 1e-10), hist   # converged (fp32: to its round-off floor)
+            errs.append(np.abs(s.get_solution().astype(np.float64) - ustar).max())
+    # u* = sin sin sin: error = C h^2 (1 + O(h^2)); fp32 adds ~1e-6 of round-off to errors of 8e-4 / 2e-4
+    assert (3.3 if f32 else 3.7) < errs[0] / errs[1] < (4.7 if f32 else 4.3), errs
+    assert errs[1] < 4e-4   # pi^2 h^2 / 12 at h = 1/64 is 2.0e-4
 
 
 def test_invalid_descriptor_is_refused():

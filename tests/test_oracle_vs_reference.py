@@ -106,6 +106,8 @@ def test_whole_solve_history(case):
     np.testing.assert_allclose(hist, ref, rtol=1e-9)
     refc = np.array([float(x) for x in case["coarse_relres"]])
     np.testing.assert_allclose([st.coarse_relres for st in stats], refc, rtol=2e-5)  # 6 s.d. print
+    # sweeps the coarse Solver spent per cycle (counting subclasses of the reference's smoothers)
+    assert [st.coarse_iters for st in stats] == case["coarse_counts"]
     ufile = np.load(os.path.join(G, "ref_solve_u.npz"))
     if case["key"] in ufile:
         np.testing.assert_allclose(s.get_solution(), ufile[case["key"]], rtol=1e-9, atol=1e-12)
