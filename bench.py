@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- V-cycles/s of the MI355X-native geometric-multigrid hot path, with the
-finest-grid smoother priced against the HBM roofline and the CPU oracle timed beside it.
+finest-grid kernels priced against the HBM roofline and the CPU oracle timed beside it.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 without RANK/WORLD_SIZE in the environment: this process only LAUNCHES -- it starts one
+child per GPU (env RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), never
+touches the GPU or imports torch itself, relays rank 0's JSON line and exits non-zero if any
+child fails or the deadline passes. Under `python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...` (WORLD_SIZE set) every process is a rank right away.
 
 Workload (BASELINE.json metric "V-cycles/sec + finest-grid smoother GB/s, 3D Poisson
 512^3"): 3-D Poisson on 513^3 nodes (nominal 512^3: vertex-centred grid, boundary nodes
@@ -12,12 +17,17 @@ weighting restriction, coarsest grid (17^3) iterated to relative residual 0.1 li
 reference's Solver (include/solvers.hpp:324-342; ~85 sweeps, LDS-resident kernel), fp64, zero
 initial guess, hash-noise right-hand side (synthetic). A step is one V-cycle.
 
-One JSON line is printed by rank 0. `roofline` prices the dominant kernel (finest-grid
-Jacobi sweep: 24 B of compulsory traffic per grid point -- read u, read rhs, write u')
-from HIP events recorded on the library's own stream INSIDE the timed region. When the library
-fuses the V(2,2) sweep pairs (k_jacobi2, two sweeps per launch) a launch processes two sweeps'
-worth of algorithmic bytes: `achieved` stays per-sweep-equivalent (24 B x points / sweep_ms) and
-`launch_ms` = 2 x `sweep_ms` is what rocprofv3 shows for that kernel.
+One JSON line is printed by rank 0. `roofline` prices the finest-grid smoother launch from HIP
+events recorded on the library's own stream INSIDE the timed region:
+  achieved = bytes the launch MUST move / launch time.  A streaming Jacobi sweep must move
+  24 B per point (read u, read rhs, write u'); the fused pair k_jacobi2 makes ONE pass for two
+  sweeps, so it must move the same 24 B per point -- `frac` is that over the 8 TB/s HBM peak and is
+  <= 1 by construction. What two streaming sweeps would have had to move per second of this
+  launch is reported separately as `sweep_equivalent_gbps` (it may exceed the peak: temporal
+  blocking). `traffic` = fabric-side bytes per launch from the committed rocprofv3 PMC passes of
+  this same command (profiles/), `traffic_frac` = traffic / launch time / peak.
+`kernels` prices the other finest-level launches of the cycle the same way, `streaming_sweep` times
+single (unfused) Jacobi sweeps of the same grid right after the timed region.
 `cpu_baseline` times the CPU oracle (our restatement of the reference algorithm; the
 reference itself has no 3-D path) on the host cores, rank 0, N=1 only.
 """
@@ -26,6 +36,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,7 +49,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -49,7 +60,7 @@ def parse():
                     help="zebra = zebra line Gauss-Seidel along y (for --aniso-y >> 1)")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cycles", type=int, default=1, help="oracle V-cycles timed for cpu_baseline")
+    ap.add_argument("--cpu-cycles", type=int, default=8, help="oracle V-cycles timed for cpu_baseline (~1 s each at 513^3)")
     ap.add_argument("--transport", choices=["rccl", "gloo"], default="rccl",
                     help="N>1 halo transport: rccl = GPU-to-GPU over xGMI (one GPU per rank, the real thing); "
                          "gloo = rehearsal through host memory, ranks may share a GPU (numbers meaningless)")
@@ -58,9 +69,81 @@ def parse():
     ap.add_argument("--aniso-eps", type=float, default=1.0, help="z-coupling multiplier eps of -(dxx + dyy + eps dzz)")
     ap.add_argument("--semi", type=int, default=0, help="number k of leading x,y-only coarsenings (mg_desc.semi_xy); "
                     "BASELINE config 5: --aniso-eps 0.01 --semi 3 --levels 8 --smoother rbgs")
-    return ap.parse_args()
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="launcher: seconds before the ranks are stopped")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="plumbing check without a GPU: ranks rendezvous over gloo, plan their slabs, time nothing")
+    ap.add_argument("--rehearse-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------ launcher
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(a, argv):
+    """Parent of an N-rank run: one child per GPU, nothing here touches the GPU. Returns the exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # rank 0's stdout carries the JSON line; everything else goes to our stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=(r == 0)))
+    deadline = time.monotonic() + a.launch_timeout
+    failed = None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+                break
+            # rank 0 is drained by communicate() below; the others are only polled
+            if all(c == 0 for c in codes[1:]):
+                break
+            if time.monotonic() > deadline:
+                failed = f"ranks still running after {a.launch_timeout:.0f} s"
+                break
+            time.sleep(0.05)
+        out0 = ""
+        if failed is None:
+            try:
+                out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                failed = f"rank 0 still running after {a.launch_timeout:.0f} s"
+            else:
+                if procs[0].returncode != 0:
+                    failed = f"rank 0 exited with code {procs[0].returncode}"
+    finally:
+        for p in procs:          # the exact children we started, nothing by pattern
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10
+        for p in procs:
+            while p.poll() is None and time.monotonic() < t_end:
+                time.sleep(0.05)
+            if p.poll() is None:
+                p.kill()
+    if failed:
+        print(f"bench.py launcher: {failed}", file=sys.stderr)
+        return 1
+    line = [l for l in out0.splitlines() if l.startswith("{")]
+    for l in out0.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if len(line) != 1:
+        print(f"bench.py launcher: expected one JSON line from rank 0, got {len(line)}", file=sys.stderr)
+        return 1
+    print(line[0])
+    return 0
+
+
+# ------------------------------------------------------------------------------------ workload
 def workload_desc(mod, a):
     return mod.make_desc(
         dim=3, n=a.n, levels=a.levels, dtype=mod.MG_F64 if a.dtype == "f64" else mod.MG_F32,
@@ -94,23 +177,48 @@ def hash_rhs(n, dtype, z0=0, nz=None, seed=12345):
     return out
 
 
+def rehearse(a, rank, world):
+    """No GPU: rendezvous, the library's host-only slab plan, one all-reduce -- the launcher's and the
+    rank bookkeeping's plumbing, exercised by tests/test_bench_launcher.py on CPU."""
+    import torch
+    import torch.distributed as dist
+    from multigrid_prj_amd import capi
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == a.rehearse_fail_rank:
+        os._exit(3)
+    desc = workload_desc(capi, a)
+    z0, nz, fg = capi.plan_slab(desc, world, rank, 0)
+    t = torch.tensor([float(nz), float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    planes = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(planes, torch.tensor([float(z0), float(nz)], dtype=torch.float64))
+    if rank == 0:
+        assert int(t[0].item()) == a.n, "slabs do not cover the grid"
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "first_gathered_level": fg, "slabs": [[int(p[0]), int(p[1])] for p in planes]}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch(a, argv))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
+        a.gpus = world   # under torch.distributed.run the environment is authoritative
+    if world > 1:
+        # a communication problem must end the run, not hang the node: every rank stops itself if the
+        # whole benchmark has not finished in time
+        import signal
+        signal.alarm(int(a.launch_timeout))
+    if a.rehearse:
+        return rehearse(a, rank, world)
 
     from multigrid_prj_amd import capi
-
-    if world > 1:
-        # a communication problem must end the run, not hang the node: every rank aborts
-        # itself if the whole benchmark has not finished in time
-        import signal
-        signal.alarm(900)
 
     dist = None
     comm_id = None
@@ -138,6 +246,7 @@ def main():
     npdt = np.float64 if a.dtype == "f64" else np.float32
     s.set_rhs(hash_rhs(a.n, npdt, z0, nz))
     s.zero_array(capi.ARR_U, 0)
+    _, _, transport_ranks, transport_name = s.comm_info()
 
     def barrier():
         s.sync()
@@ -150,43 +259,93 @@ def main():
     # convergence sanity of the benchmarked cycle (not timed), from the zero guess so the ratio is not
     # taken at the round-off floor: asymptotic residual reduction per cycle. Done BEFORE the timed
     # region: it also brings the clocks up and loads every kernel, so that short runs (small W) measure
-    # the same steady state as long ones; u is zeroed again afterwards.
+    # the same steady state as long ones; u is zeroed again afterwards. The same loop gives the cost of the
+    # per-cycle residual norm mg_solve adds to a cycle (`value` counts bare cycles, mg_cycle_async).
     hist, _ = s.solve(0.0, 4)
     s.zero_array(capi.ARR_U, 0)
     barrier()
     # warmup (untimed)
     s.cycle_async(a.warmup)
     barrier()
-    # timed region: exactly K cycles, finest-grid smoother bracketed by HIP events
+    # timed region: exactly K cycles, finest-level launches bracketed by HIP events
     s.profile_begin()
     t0 = time.perf_counter()
     s.cycle_async(a.steps)
     barrier()
     t1 = time.perf_counter()
-    sm_ms, sm_sweeps = s.profile_end()
-    fu_ms, fu_sweeps = s.profile_fused()   # post-smoothing pairs that also carried the prolongation
+    _, sm_sweeps = s.profile_end()
+    prof = {k: s.profile_get(getattr(capi, "PROF_" + k)) for k in ("SMOOTH", "SMOOTH_PROLONG", "RESID_RESTRICT", "PROLONG")}
     elapsed = t1 - t0
+    per_rank_ms = [1e3 * elapsed / a.steps]
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if a.transport == "rccl" else "cpu")
+        dev = "cuda" if a.transport == "rccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [1e3 * float(x.item()) / a.steps for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # mg_solve's cycle = this cycle + one finest-grid residual norm: time a few of them for the record
+    barrier()
+    s.zero_array(capi.ARR_U, 0)
+    ts0 = time.perf_counter()
+    s.solve(0.0, 6)
+    barrier()
+    solve_ms_per_cycle = 1e3 * (time.perf_counter() - ts0) / 6
+
+    # single streaming sweeps of the finest grid (the unfused kernel the fused pair replaces)
+    stream_ms = None
+    if world == 1 and a.smoother == "jacobi":
+        s.smooth(0, capi.SMOOTH_JACOBI, 1, capi.ARR_U, capi.ARR_RHS)
+        s.timer_start()
+        for _ in range(9):
+            s.smooth(0, capi.SMOOTH_JACOBI, 1, capi.ARR_U, capi.ARR_RHS)
+        stream_ms = s.timer_stop() / 9
 
     ms_per_step = 1e3 * elapsed / a.steps
     cycles_per_s = a.steps / elapsed
     esz = 8 if a.dtype == "f64" else 4
     pts_local = nz * a.n * a.n
-    bytes_per_sweep = 3 * esz * pts_local          # read u, read rhs, write u'
-    sweep_ms = sm_ms / max(sm_sweeps, 1)
-    achieved = bytes_per_sweep / (sweep_ms * 1e-3) / 1e9 if sm_sweeps else 0.0
+    sweep_bytes = 3 * esz * pts_local                 # read u, read rhs, write u': what one pass must move
+    sm_ms, sm_launches = prof["SMOOTH"]
+    sweeps_timed = sm_sweeps                            # sweeps those launches performed
+    launch_ms = sm_ms / max(sm_launches, 1)
+    sweeps_per_launch = sweeps_timed / max(sm_launches, 1)
+    achieved = sweep_bytes / (launch_ms * 1e-3) / 1e9 if sm_launches else 0.0
+    fused_pair = sweeps_per_launch > 1.5
 
-    traffic, traffic_src = profiled_traffic(a) if world == 1 else (None, None)
-    # On a whole (non-distributed) level whose rows are 64/128/256 vectors wide the library runs
-    # the V(2,2) sweep pairs as ONE launch (k_jacobi2: two sweeps per pass over HBM).
-    vec = 2 if a.dtype == "f64" else 4
-    fused_pair = (a.smoother == "jacobi" and world == 1 and (a.n - 1) % vec == 0 and (a.n - 1) // vec in (64, 128, 256)
-                  and os.environ.get("MG_FUSED_PAIR", "1") != "0")
-    sweeps_per_launch = 2 if fused_pair else 1
+    traffic_rows = profiled_traffic(a) if world == 1 else {}
+    tr = traffic_rows.get("pair" if fused_pair else "single")
+    traffic = tr["bytes"] if tr else None
+    # arrays beyond the 256 MB Infinity Cache stream from HBM: their compulsory bytes cannot move faster than the peak
+    assert achieved <= HBM_PEAK_GBS or pts_local * esz <= (256 << 20), "frac > 1 on an HBM-resident level"
+
+    def priced(kind, label, must_move, replaces, tkey):
+        ms, n = prof[kind]
+        if not n:
+            return None
+        lm = ms / n
+        row = traffic_rows.get(tkey)
+        return {"kernel": label, "launch_ms": lm, "launches_timed": n, "compulsory_bytes": int(must_move),
+                "achieved": must_move / (lm * 1e-3) / 1e9, "frac": must_move / (lm * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "replaces_bytes": int(replaces), "equivalent_gbps": replaces / (lm * 1e-3) / 1e9,
+                "traffic": row["bytes"] if row else None,
+                "traffic_frac": row["bytes"] / (lm * 1e-3) / 1e9 / HBM_PEAK_GBS if row else None}
+
+    pts_c = ((a.n + 1) // 2) ** 2 * (a.n if a.semi else (a.n + 1) // 2)
+    kernels = [k for k in (
+        # J(J(u + P e)): reads u, the coarse correction (1/8 of the points) and rhs, writes once
+        priced("SMOOTH_PROLONG", "post-smoothing launch that also applies the coarse correction (k_jacobi2<CORR>)",
+               sweep_bytes + esz * pts_c, 2 * sweep_bytes + 2 * esz * pts_local + esz * pts_c, "corr"),
+        # R(rhs - A u): reads u and rhs, writes the coarse right-hand side
+        priced("RESID_RESTRICT", "finest-level residual + full-weighting restriction (k_resid_restrict_fw)",
+               2 * esz * pts_local + esz * pts_c, 3 * esz * pts_local + esz * (pts_local + pts_c), "rr"),
+        priced("PROLONG", "separate prolongation into the finest level", 2 * esz * pts_local + esz * pts_c,
+               2 * esz * pts_local + esz * pts_c, "prolong"),
+    ) if k]
+
     out = {
         "metric": f"V-cycles/sec (3D Poisson {a.n}^3 V(2,2)) + finest-grid smoother GB/s vs HBM roofline",
         "value": cycles_per_s, "unit": "V-cycles/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -200,26 +359,29 @@ def main():
                                   f"coarse {((a.n - 1) >> (a.levels - 1)) + 1}^3 iterated to rel. residual 0.1, {a.dtype}"),
                    "parallelism": (f"z-slab x{world}" + ("" if a.transport == "rccl" else " (gloo rehearsal)")) if world > 1 else "single GPU",
                    "first_gathered_level": first_gathered},
+        "transport": transport_name, "rccl_ranks": transport_ranks if transport_name == "rccl" else None,
+        "ms_per_step_ranks": per_rank_ms,
+        "ms_per_step_with_residual_norm": solve_ms_per_cycle,
         "roofline": {"bound": "hbm",
-                     "kernel": (f"finest-grid fused double Jacobi sweep k_jacobi2 ({a.n}^3, 2 sweeps per launch)" if fused_pair
+                     "kernel": (f"finest-grid fused double Jacobi sweep k_jacobi2 ({a.n}^3, two sweeps in one pass over HBM)" if fused_pair
                                 else f"finest-grid {a.smoother} sweep ({a.n}^3)"),
-                     "sweeps_per_launch": sweeps_per_launch, "launch_ms": sweep_ms * sweeps_per_launch,
-                     "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_src, "sweep_ms": sweep_ms, "sweeps_timed": sm_sweeps,
-                     "algorithmic_bytes_per_sweep": bytes_per_sweep,
-                     "note": ("temporal blocking: one launch performs two sweeps in one pass over HBM, so the algorithmic "
-                              "two-sweep bytes per launch can exceed what a streaming kernel could move; `traffic` is the "
-                              "measured fabric-side traffic of that launch" if fused_pair else None)},
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "traffic_source": tr["source"] if tr else None,
+                     "launch_ms": launch_ms, "launches_timed": sm_launches, "sweeps_per_launch": sweeps_per_launch,
+                     "compulsory_bytes_per_launch": sweep_bytes,
+                     "sweep_ms": launch_ms / sweeps_per_launch,
+                     "sweep_equivalent_gbps": sweeps_per_launch * sweep_bytes / (launch_ms * 1e-3) / 1e9,
+                     "note": ("achieved = 24 B/pt (read u, read rhs, write once) / launch time: the launch makes one pass for "
+                              "two sweeps; sweep_equivalent_gbps = what two streaming sweeps would have moved per second "
+                              "of it" if fused_pair else None)},
         "smoother_gbps": achieved,
-        # one launch = prolong-add (read u, read coarse, write u: not executed as such) + two sweeps
-        "prolong_folded_pair": ({"kernel": ("k_jacobi2<CORR>: J(J(u + P e)) in one pass" if a.smoother == "jacobi"
-                                            else "post-smoothing segment: RB(u + P e) in one pass, then the remaining sweep(s)"),
-                                 "launch_ms": 2 * fu_ms / fu_sweeps,
-                                 "launches_timed": fu_sweeps // 2,
-                                 "replaces_bytes": 2 * bytes_per_sweep + int(2.125 * esz * pts_local),
-                                 "equivalent_gbps": (2 * bytes_per_sweep + 2.125 * esz * pts_local) / (2 * fu_ms / fu_sweeps * 1e-3) / 1e9}
-                                if fu_sweeps else None),
+        "kernels": kernels,
+        "streaming_sweep": ({"kernel": f"single Jacobi sweep k_sweep3d ({a.n}^3), timed after the region", "launch_ms": stream_ms,
+                             "achieved": sweep_bytes / (stream_ms * 1e-3) / 1e9,
+                             "frac": sweep_bytes / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": traffic_rows["single"]["bytes"] if "single" in traffic_rows else None}
+                            if stream_ms else None),
         "residual_drop_per_cycle": float(hist[-1] / hist[-2]) if len(hist) >= 2 and hist[-2] > 0 else None,
         "device_bytes": s.device_bytes(),
     }
@@ -233,27 +395,49 @@ def main():
         dist.destroy_process_group()
 
 
+def _template_args(name):
+    i, j = name.find("<"), name.rfind(">")
+    return [x.strip() for x in name[i + 1:j].split(",")] if 0 <= i < j else []
+
+
 def profiled_traffic(a):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
-    this same command (profiles/r01_kernel_summary.csv, made by tools/profile.sh +
-    tools/summarize_prof.py: separate --pmc FETCH_SIZE / WRITE_SIZE passes, read = 2 x FETCH_SIZE
-    x 1024 on gfx950). Counters cannot be collected inside a timed run, so this is not live;
-    None when the workload is not the profiled default."""
+    """HBM-side bytes per launch of the finest-level kernels from the committed rocprofv3 PMC passes of
+    this same command (profiles/r*_kernel_summary.csv, made by tools/profile.sh + tools/summarize_prof.py:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes, read = 2 x FETCH_SIZE x 1024 on gfx950). Counters cannot
+    be collected inside a timed run, so this is not live; rows are picked by exact template signature and
+    the finest grid's launch size. Empty when the workload is not the profiled default."""
     if not (a.n == 513 and a.dtype == "f64" and a.smoother == "jacobi" and a.levels == 6 and not a.semi):
-        return None, None
-    fused = os.environ.get("MG_FUSED_PAIR", "1") != "0"
-    path = os.path.join(ROOT, "profiles", "r01_kernel_summary.csv")
-    if not os.path.exists(path):
-        return None, None
+        return {}
     import csv
-    best = None
-    for r in csv.DictReader(open(path)):
-        if r["kernel"].startswith("k_jacobi2<double" if fused else "k_sweep3d<double, 0,") and r["read_MB"] and r["write_MB"]:
-            if best is None or int(r["grid_threads"]) > int(best["grid_threads"]):
-                best = r
-    if best is None:
-        return None, None
-    return (float(best["read_MB"]) + float(best["write_MB"])) * 1e6, "profiles/r01_kernel_summary.csv (rocprofv3 --pmc passes of this command)"
+    import glob
+    rows = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_summary*.csv"))):
+        src = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc passes of this command)"
+        best = {}
+        for r in csv.DictReader(open(path)):
+            if not (r["read_MB"] and r["write_MB"]):
+                continue
+            t = _template_args(r["kernel"])
+            key = None
+            if r["kernel"].startswith("k_jacobi2<") and t[:2] == ["double", "256"]:
+                # <T, TPR, DAMPED, NTLOAD, CORR, RB, ZEROU, TYO>
+                if t[4:7] == ["false", "false", "false"]:
+                    key = "pair"
+                elif t[4:7] == ["true", "false", "false"]:
+                    key = "corr"
+            elif r["kernel"].startswith("k_sweep3d<") and t[:2] == ["double", "0"] and t[-1] == "false":
+                key = "single"
+            elif r["kernel"].startswith("k_resid_restrict_fw<") and t[:1] == ["double"]:
+                key = "rr"
+            elif r["kernel"].startswith("k_prolong3d_fast<") and t[:1] == ["double"]:
+                key = "prolong"
+            if key and (key not in best or int(r["grid_threads"]) > int(best[key]["grid_threads"])):
+                best[key] = r
+        for key, r in best.items():   # later rounds' files win
+            if key == "single" and int(r["grid_threads"]) < 10_000_000:
+                continue              # only a finest-grid launch (11.4 M threads) prices the streaming sweep
+            rows[key] = {"bytes": (float(r["read_MB"]) + float(r["write_MB"])) * 1e6, "source": src, "kernel": r["kernel"]}
+    return rows
 
 
 def cpu_baseline(a):

@@ -152,6 +152,13 @@ int mg_profile_end(mg_handle h, double *smoother_ms, int *smoother_sweeps);
  * launch computing J(J(u + P e))); those segments are not smoother-only work, so they are
  * left out of mg_profile_end's totals and reported here (valid after mg_profile_end). */
 int mg_profile_fused(mg_handle h, double *fused_ms, int *fused_sweeps);
+/* The same events, by kind of finest-level launch (valid after mg_profile_end): summed milliseconds and
+ * number of launches of  MG_PROF_SMOOTH          smoother launches (a fused pair is ONE launch of two sweeps)
+ *                        MG_PROF_SMOOTH_PROLONG  the post-smoothing launch that also applies P e
+ *                        MG_PROF_RESID_RESTRICT  residual + restriction of level 0 (fused or as two kernels)
+ *                        MG_PROF_PROLONG         separate prolongation into level 0 */
+enum mg_prof_kind { MG_PROF_SMOOTH = 0, MG_PROF_SMOOTH_PROLONG = 1, MG_PROF_RESID_RESTRICT = 2, MG_PROF_PROLONG = 3, MG_PROF_KINDS = 4 };
+int mg_profile_get(mg_handle h, int kind, double *ms, int *launches);
 /* bytes of HBM held by the handle */
 int mg_device_bytes(mg_handle h, size_t *bytes);
 
@@ -163,6 +170,9 @@ int mg_comm_unique_id(void *id128);
 /* single-process smoke test of the RCCL transport on the current device: communicator of
  * one rank, grouped send/recv to self of `bytes` bytes, all-reduce of one double */
 int mg_comm_selftest(size_t bytes);
+/* rank / size of the handle's decomposition and what the transport itself reports (RCCL: ncclCommCount;
+ * 1 for a single-GPU handle); transport = "none" | "rccl" | "host-callbacks" (static string) */
+int mg_comm_info(mg_handle h, int *rank, int *nranks, int *transport_ranks, const char **transport);
 /* like mg_create, for rank `rank` of `nranks` (one process per GPU) */
 int mg_create_distributed(const mg_desc *desc, int device, int rank, int nranks,
                           const void *id128, mg_handle *out);

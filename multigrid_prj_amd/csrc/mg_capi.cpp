@@ -175,6 +175,17 @@ int mg_timer_stop(mg_handle h, double *ms) { MG_H(h); return guarded([&] { retur
 int mg_profile_begin(mg_handle h) { MG_H(h); return guarded([&] { return h->impl->profile_begin(); }); }
 int mg_profile_end(mg_handle h, double *ms, int *sweeps) { MG_H(h); return guarded([&] { return h->impl->profile_end(ms, sweeps); }); }
 int mg_profile_fused(mg_handle h, double *ms, int *sweeps) { MG_H(h); return guarded([&] { return h->impl->profile_fused(ms, sweeps); }); }
+int mg_profile_get(mg_handle h, int kind, double *ms, int *launches)
+{
+    MG_H(h);
+    if (kind < 0 || kind >= MG_PROF_KINDS) return bad("mg_profile_get: unknown kind");
+    return guarded([&] { return h->impl->profile_get(kind, ms, launches); });
+}
+int mg_comm_info(mg_handle h, int *rank, int *nranks, int *transport_ranks, const char **transport)
+{
+    MG_H(h);
+    return guarded([&] { return h->impl->comm_info(rank, nranks, transport_ranks, transport); });
+}
 int mg_device_bytes(mg_handle h, size_t *bytes)
 {
     MG_H(h);

@@ -27,6 +27,9 @@ public:
     virtual int batch(const P2POp *ops, int n, hipStream_t s) = 0;
     // in-place sum of n device doubles over all ranks, on stream `s`
     virtual int allreduce_sum(double *dptr, int n, hipStream_t s) = 0;
+    // ranks the transport itself reports (RCCL: ncclCommCount), for mg_comm_info
+    virtual int transport_ranks() const { return nranks; }
+    virtual const char *name() const = 0;
     int rank = 0, nranks = 1;
 };
 

@@ -19,6 +19,12 @@ class RcclComm : public Comm {
 public:
     ncclComm_t comm = nullptr;
     ~RcclComm() override { if (comm) ncclCommDestroy(comm); }
+    int transport_ranks() const override
+    {
+        int n = 0;
+        return (comm && ncclCommCount(comm, &n) == ncclSuccess) ? n : -1;
+    }
+    const char *name() const override { return "rccl"; }
     int batch(const P2POp *ops, int n, hipStream_t s) override
     {
         if (n == 0) return MG_OK;
@@ -75,6 +81,7 @@ public:
     std::vector<char *> stage;  // pinned staging buffers, one per op slot
     std::vector<size_t> cap;
     double *hscal = nullptr;
+    const char *name() const override { return "host-callbacks"; }
     ~HostComm() override
     {
         for (char *p : stage) if (p) (void)hipHostFree(p);

@@ -632,21 +632,15 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
     Level &L = lv_[level];
     Coef<T> c = coef_of<T>(L);
     const bool prof = profiling_ && level == 0 && sweeps > 0 && smoother != MG_SMOOTH_GS_LEX;
-    if (prof) {
-        if (prof_used_ + 2 > prof_ev_.size()) {
-            size_t old = prof_ev_.size();
-            prof_ev_.resize(old + 256);
-            for (size_t i = old; i < prof_ev_.size(); i++) MG_HIP(hipEventCreate(&prof_ev_[i]));
-        }
-        MG_HIP(hipEventRecord(prof_ev_[prof_used_], stream_));
-    }
+    int launches = 0;  // kernel launches of this call (a fused pair is one)
+    if (prof) MG_TRY(prof_begin(level));
     switch (smoother) {
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
             if (L.dist && overlap_ && d_.cycle == MG_CYCLE_V && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps &&
                 !(x_zero && s == 0) && jacobi2_slab_ok<T>(L.g)) {  // E is free in a V-cycle: scratch for the boundary planes' first sweep
                 MG_TRY(pair_on_slab_t<T>(level, false));
-                s++;
+                s++; launches += 5;
                 continue;
             }
             if (!L.dist && s + 1 < sweeps && jacobi2_ok<T>(L.g)) {
@@ -658,9 +652,10 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
                     launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
                                       x_zero && s == 0);
                 std::swap(L.base[ax], L.base[MG_ARR_TMP]);
-                s++;
+                s++; launches++;
                 continue;
             }
+            launches++;
             const bool zero_now = x_zero && s == 0;
             T *px = ptr<T>(ax, level), *pr = ptr<T>(ar, level), *pt = ptr<T>(MG_ARR_TMP, level);
             if (zero_now) {
@@ -679,6 +674,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
             if (L.dist && overlap_ && d_.cycle == MG_CYCLE_V && ax == MG_ARR_U && ar == MG_ARR_RHS &&
                 jacobi2_slab_ok<T>(L.g) && rb_slab_enabled()) {  // one-pass red-black sweep on the slab's inner planes
                 MG_TRY(pair_on_slab_t<T>(level, true));
+                launches += 5;
                 continue;
             }
             if (!L.dist && rb_fused_ok<T>(L.g)) {  // both colours in one pass over HBM; the sweep lands in TMP
@@ -686,8 +682,10 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
                 launch_rb_fused<T>(stream_, L.g, c, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
                                    corr ? ptr<T>(ax, corr_level) : (const T *)nullptr, lv_[corr ? corr_level : level].g);
                 std::swap(L.base[ax], L.base[MG_ARR_TMP]);
+                launches++;
                 continue;
             }
+            launches += 2;
             if (fast_path_ok<T>(L.g)) {  // vectorised, out of place: red x -> tmp, black tmp -> x
                 T *px = ptr<T>(ax, level), *pr = ptr<T>(ar, level), *pt = ptr<T>(MG_ARR_TMP, level);
                 MG_TRY(overlapped(level, ax, [&](const Geom &gs, long long off) {
@@ -709,6 +707,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
             set_last_error("zebra line smoother: the handle was not created with MG_SMOOTH_ZEBRA_Y");
             return MG_ERR_BAD_ARG;
         }
+        launches += 2 * sweeps;
         for (int s = 0; s < sweeps; s++)
             for (int colour = 0; colour < 2; colour++) {
                 MG_TRY(exchange(ax, level));  // the other colour's ghost planes (z-slabs; lines run along y)
@@ -724,11 +723,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
         if (sweeps > 0) launch_gs_lex<T>(stream_, L.g, c, sweeps, ptr<T>(ax, level), ptr<T>(ar, level));
         break;
     }
-    if (prof) {
-        MG_HIP(hipEventRecord(prof_ev_[prof_used_ + 1], stream_));
-        prof_used_ += 2;
-        prof_kind_.push_back(corr_level >= 0 ? sweeps : -sweeps);  // > 0: segment also carries the prolongation
-    }
+    if (prof) MG_TRY(prof_end(level, corr_level >= 0 ? MG_PROF_SMOOTH_PROLONG : MG_PROF_SMOOTH, sweeps, launches));
     MG_HIP(hipGetLastError());
     return MG_OK;
 }
@@ -981,8 +976,10 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
     // fused residual + full weighting when both levels live whole on this rank
     const bool fuse_rr = mine && d_.restriction == MG_RESTRICT_FULLW && !lv_[l].dist && lv_[l + 1].present &&
                          resid_restrict_fast_ok<T>(lv_[l].g, lv_[l + 1].g);
+    const bool prof = profiling_ && l == 0 && mine;
     if (mine) {
         MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero));
+        if (prof) MG_TRY(prof_begin(l));
         if (!fuse_rr) MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
     }
     if (lv_[l].dist && !lv_[l + 1].dist) {  // l == T_: restrict locally, gather the coarse rhs on rank 0
@@ -993,6 +990,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
             launch_inject<T>(stream_, lv_[l].g, stage_g_, ptr<T>(MG_ARR_TMP, l), stageptr<T>(0));
         }
         MG_HIP(hipGetLastError());
+        if (prof) MG_TRY(prof_end(l, MG_PROF_RESID_RESTRICT, 1, 2));
         MG_TRY(gather_S(MG_ARR_RHS));
         if (rank_ == 0) {
             const bool skip0 = can_skip_zeroing<T>(l + 1);
@@ -1000,8 +998,10 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
             MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
         }
         MG_TRY(scatter_S(MG_ARR_U));
+        if (prof) MG_TRY(prof_begin(l));
         launch_prolong<T>(stream_, stage_g_, lv_[l].g, stageptr<T>(1), ptr<T>(MG_ARR_U, l), true);
         MG_HIP(hipGetLastError());
+        if (prof) MG_TRY(prof_end(l, MG_PROF_PROLONG, 1, 1));
     } else if (mine) {
         if (fuse_rr) {
             launch_resid_restrict_fw<T>(stream_, lv_[l].g, lv_[l + 1].g, coef_of<T>(lv_[l]), ptr<T>(MG_ARR_U, l),
@@ -1010,11 +1010,16 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         } else {
             MG_TRY(restrict_t<T>(l, d_.restriction, MG_ARR_TMP, MG_ARR_RHS));
         }
+        if (prof) MG_TRY(prof_end(l, MG_PROF_RESID_RESTRICT, 1, fuse_rr ? 1 : 2));
         const bool skip0 = can_skip_zeroing<T>(l + 1);
         if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
         MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
         fold = can_fold_prolong<T>(l);
-        if (!fold) MG_TRY(prolong_t<T>(l + 1, 1, MG_ARR_U, MG_ARR_U));
+        if (!fold) {
+            if (prof) MG_TRY(prof_begin(l));
+            MG_TRY(prolong_t<T>(l + 1, 1, MG_ARR_U, MG_ARR_U));
+            if (prof) MG_TRY(prof_end(l, MG_PROF_PROLONG, 1, 1));
+        }
     }
     if (mine) MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS, false, fold ? l + 1 : -1));
     return MG_OK;
@@ -1165,12 +1170,33 @@ int Solver::sync()
     return MG_OK;
 }
 
+int Solver::prof_begin(int)
+{
+    if (prof_used_ + 2 > prof_ev_.size()) {
+        size_t old = prof_ev_.size();
+        prof_ev_.resize(old + 256);
+        for (size_t i = old; i < prof_ev_.size(); i++) MG_HIP(hipEventCreate(&prof_ev_[i]));
+    }
+    MG_HIP(hipEventRecord(prof_ev_[prof_used_], stream_));
+    return MG_OK;
+}
+
+int Solver::prof_end(int, int kind, int units, int launches)
+{
+    MG_HIP(hipEventRecord(prof_ev_[prof_used_ + 1], stream_));
+    prof_used_ += 2;
+    prof_kind_.push_back(kind);
+    prof_units_.push_back(units);
+    prof_launches_.push_back(launches);
+    return MG_OK;
+}
+
 int Solver::profile_begin()
 {
     profiling_ = true;
     prof_used_ = 0;
     prof_sweeps_ = 0;
-    prof_kind_.clear();
+    prof_kind_.clear(); prof_units_.clear(); prof_launches_.clear();
     return MG_OK;
 }
 
@@ -1181,12 +1207,14 @@ int Solver::profile_end(double *ms, int *sweeps)
     profiling_ = false;
     double tot = 0;
     prof_sweeps_ = 0; prof_fused_ms_ = 0; prof_fused_sweeps_ = 0;
+    for (int k = 0; k < MG_PROF_KINDS; k++) { prof_ms_[k] = 0; prof_n_[k] = 0; }
     for (size_t i = 0; i + 1 < prof_used_; i += 2) {
         float f = 0;
         MG_HIP(hipEventElapsedTime(&f, prof_ev_[i], prof_ev_[i + 1]));
         const int k = prof_kind_[i / 2];
-        if (k > 0) { prof_fused_ms_ += f; prof_fused_sweeps_ += k; }
-        else { tot += f; prof_sweeps_ += -k; }
+        prof_ms_[k] += f; prof_n_[k] += prof_launches_[i / 2];
+        if (k == MG_PROF_SMOOTH_PROLONG) { prof_fused_ms_ += f; prof_fused_sweeps_ += prof_units_[i / 2]; }
+        else if (k == MG_PROF_SMOOTH) { tot += f; prof_sweeps_ += prof_units_[i / 2]; }
     }
     if (ms) *ms = tot;
     if (sweeps) *sweeps = prof_sweeps_;
@@ -1197,6 +1225,22 @@ int Solver::profile_fused(double *ms, int *sweeps) const
 {
     if (ms) *ms = prof_fused_ms_;
     if (sweeps) *sweeps = prof_fused_sweeps_;
+    return MG_OK;
+}
+
+int Solver::profile_get(int kind, double *ms, int *launches) const
+{
+    if (ms) *ms = prof_ms_[kind];
+    if (launches) *launches = prof_n_[kind];
+    return MG_OK;
+}
+
+int Solver::comm_info(int *rank, int *nranks, int *transport_ranks, const char **transport) const
+{
+    if (rank) *rank = rank_;
+    if (nranks) *nranks = nranks_;
+    if (transport_ranks) *transport_ranks = comm_ ? comm_->transport_ranks() : 1;
+    if (transport) *transport = comm_ ? comm_->name() : "none";
     return MG_OK;
 }
 

@@ -78,6 +78,8 @@ public:
     int profile_begin();
     int profile_end(double *ms, int *sweeps);
     int profile_fused(double *ms, int *sweeps) const;
+    int profile_get(int kind, double *ms, int *launches) const;
+    int comm_info(int *rank, int *nranks, int *transport_ranks, const char **transport) const;
     size_t device_bytes() const { return bytes_; }
 
     const mg_desc &desc() const { return d_; }
@@ -163,9 +165,16 @@ private:
     std::vector<hipEvent_t> prof_ev_;
     size_t prof_used_ = 0;
     int prof_sweeps_ = 0;
-    std::vector<int> prof_kind_;   // per event pair: -sweeps (plain) or +sweeps (carries the prolongation)
+    std::vector<int> prof_kind_;   // per event pair: mg_prof_kind
+    std::vector<int> prof_units_;  // per event pair: sweeps (smoother kinds) or 1
+    std::vector<int> prof_launches_;
     double prof_fused_ms_ = 0;
     int prof_fused_sweeps_ = 0;
+    double prof_ms_[MG_PROF_KINDS] = {};
+    int prof_n_[MG_PROF_KINDS] = {};
+    // brackets [begin, end) with HIP events when profiling the finest level
+    int prof_begin(int level);
+    int prof_end(int level, int kind, int units, int launches);
 };
 
 }  // namespace mg

@@ -1,0 +1,42 @@
+"""`python3 bench.py --gpus N` as the driver types it: without RANK/WORLD_SIZE in the environment the process
+only launches one child per rank and relays rank 0's JSON line. CPU rehearsal (--rehearse: gloo rendezvous,
+the library's host-only slab plan, no GPU) of exactly that plumbing, world size 2 and 3."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _run(args, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_self_launches_its_ranks(world):
+    p = _run(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--rehearse", "--grid", "129", "--levels", "4", "--dist-min-n", "33"])
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and p.stdout.strip() == lines[0]      # ONE JSON line on stdout, nothing else
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["steps"] == 3 and out["warmup"] == 1
+    slabs = out["slabs"]
+    assert slabs[0][0] == 0 and sum(nz for _, nz in slabs) == 129
+    assert all(slabs[r][0] == slabs[r - 1][0] + slabs[r - 1][1] for r in range(1, world))
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    p = _run(["--gpus", "2", "--rehearse", "--grid", "65", "--levels", "3", "--rehearse-fail-rank", "1", "--launch-timeout", "60"])
+    assert p.returncode != 0 and "rank 1 exited with code 3" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_launcher_deadline():
+    """A rank that never finishes (here: rank 1 waits for a rendezvous rank 0 never joins) ends the run."""
+    p = _run(["--gpus", "2", "--rehearse", "--grid", "65", "--levels", "3", "--rehearse-fail-rank", "0", "--launch-timeout", "20"])
+    assert p.returncode != 0
