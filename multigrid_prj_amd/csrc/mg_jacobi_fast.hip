@@ -448,15 +448,16 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
     for (int p = z0 - 1; p <= z1; p++) {
         const long long po = plane_of(p);
         const T *pu = u + po;
-        // planes outside the global grid (first / last chunk only) are never evaluated: their v only
-        // feeds Dirichlet outputs and stays zero
-        const bool pin = (gzo + p >= 0) && (gzo + p < gzn);  // a plane of the global grid
+        // Planes p = -1 and p = nz of the global grid (first / last chunk only) are evaluated like any other, on the
+        // ghost planes: their v only feeds the outputs of the Dirichlet planes 0 and nz-1, which are selected from rhs.
+        // (A uniform test that skipped them cost ~45 zero-initialising moves per plane step and 5-9 VGPRs: the
+        // prolongation-folding variant spilled two of them, 1.00-1.08 -> 0.975 ms per launch without the test.)
         vec b[TYV], v[TYV];
         T vtail[TYV];
 #pragma unroll
         for (int r = 0; r < TYV; r++) {
             up[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (plane_of(p + 1) + urow[r])) + x0);
-            b[r] = (vec)(0); v[r] = (vec)(0); vtail[r] = 0;
+            vtail[r] = 0;
         }
         // ---- every load of this step first ...
         T Ra[4][NR], Rb[4][NR];  // CORR: raw coarse values under plane p+1
@@ -473,15 +474,14 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
             ter_n[r] = 0;
             if (tail && !ZEROU) ter_n[r] = (u + (plane_of(p + 1) + urow[r]))[x0 + V];
         }
-        if (pin) {
+        {
             if (!CORR && !ZEROU) {
                 hlo = *(const vec *)((pu + urow_lo) + x0);
                 hhi = *(const vec *)((pu + urow_hi) + x0);
             }
 #pragma unroll
             for (int r = 0; r < TYV; r++) {
-                if (NTLOAD && r >= 1 && r <= TYO) b[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
-                else b[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
+                b[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
                 if (tail) vtail[r] = (rhs + (po + urow[r]))[x0 + V];  // first sweep on the Dirichlet column: v = rhs
             }
         }
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
             hlo_n = add_vec(hlo_n, pe_vec(Yn[0])); hhi_n = add_vec(hhi_n, pe_vec(Yn[5]));
         }
         publish_edges((p + 1) & 1, up, ter_n);
-        if (pin) {
+        {
             const bool zbp = (gzo + p == 0) || (gzo + p == gzn - 1);
 #pragma unroll
             for (int r = 0; r < TYV; r++) {
@@ -593,14 +593,6 @@ __global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, 
                         }
                     }
                 }
-            }
-        }
-        if (!pin) {  // planes outside the grid: their slot must still hold the zeros the second sweep reads
-            const int sl = p & 1;
-#pragma unroll
-            for (int r = 0; r < TYV; r++) {
-                *(vec *)&lds[sl][r][V + x0] = v[r];
-                if (tail) lds[sl][r][V + x0 + V] = vtail[r];
             }
         }
         __syncthreads();

@@ -50,6 +50,10 @@ def main():
             if r["Counter_Name"] == cname:
                 acc[(short(r["Kernel_Name"]), int(r["Grid_Size"]), int(r["Workgroup_Size"]))].append(float(r["Counter_Value"]))
         pmc[cname] = acc
+    sq = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in newest(os.path.join(src, "pmc_sq", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            sq[(short(r["Kernel_Name"]), int(r["Grid_Size"]), int(r["Workgroup_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     bench = {}
     bj = os.path.join(src, "bench_trace.json")
     if os.path.exists(bj):
@@ -77,6 +81,19 @@ def main():
         lines.append(f"| `{key[0]}` | {key[1]} | {key[2]} | {len(durs)} | {tot / len(durs) / 1e3:.2f} | {min(durs) / 1e3:.2f} | "
                      f"{tot / 1e6:.3f} | {100 * tot / total:.1f} | {v[0][1]} | {f(rd_mb)} | {f(wr_mb)} |")
         rows_csv.append((key[0], key[1], key[2], len(durs), tot / len(durs) / 1e3, min(durs) / 1e3, tot / 1e6, 100 * tot / total, v[0][1], rd_mb, wr_mb))
+    if sq:
+        lines += ["", "Wave-cycle breakdown (own `--pmc SQ_*` pass; quad-cycles summed over all waves, per launch): parked = SQ_WAIT_ANY "
+                  "(s_waitcnt / barrier), stalled = SQ_WAIT_INST_ANY (issue stall), issuing = SQ_ACTIVE_INST_ANY; VALU / SALU = instructions issued.", "",
+                  "| kernel | grid | wave-cycles | parked % | issue-stalled % | issuing % | of which VALU % / scalar % | VALU insts per wave-cycle | SALU:VALU insts |", "|---|---|---|---|---|---|---|---|---|"]
+        for key, v in sorted(groups.items(), key=lambda kv: -sum(d for d, *_ in kv[1])):
+            c = sq.get(key)
+            if not c or sum(d for d, *_ in v) / total < 0.01:
+                continue
+            m = {k: sum(x) / len(x) for k, x in c.items()}
+            wc = m.get("SQ_WAVE_CYCLES", 0) or 1
+            lines.append(f"| `{key[0]}` | {key[1]} | {wc:.3g} | {100 * m.get('SQ_WAIT_ANY', 0) / wc:.0f} | {100 * m.get('SQ_WAIT_INST_ANY', 0) / wc:.0f} | "
+                         f"{100 * m.get('SQ_ACTIVE_INST_ANY', 0) / wc:.0f} | {100 * m.get('SQ_ACTIVE_INST_VALU', 0) / wc:.0f} / {100 * m.get('SQ_ACTIVE_INST_SCA', 0) / wc:.0f} | "
+                         f"{m.get('SQ_INSTS_VALU', 0) / wc:.3f} | {m.get('SQ_INSTS_SALU', 0) / max(m.get('SQ_INSTS_VALU', 1), 1):.2f} |")
     lines += ["", "Traffic columns: PMC counters from their own passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950), "
               "per launch, with the gfx950 correction read = 2 × FETCH_SIZE × 1024 B (MI355X_MICROARCH.md §HBM); "
               "Infinity-Cache hits are counted as traffic by these fabric-side counters.", ""]
