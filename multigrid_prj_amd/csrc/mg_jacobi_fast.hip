@@ -681,7 +681,14 @@ int launch_residual_fast(hipStream_t s, const Geom &g, const Coef<T> &c, const T
     return want_norm ? f.grid : 0;
 }
 
-// fused double sweep: whole (non-distributed) 3-D level whose rows are exactly 64/128/256 vectors
+// Row widths of the fused kernels: the workgroup is one whole grid row of TPR vectors + the odd column, TPR a
+// multiple of the wave size: 64 / 128 / 256 (n = 2^k + 1 grids) and 192 / 384 / 512 (n = 385, 769, 1025 in fp64:
+// the reference's own 385 fixture size, and BASELINE config 4's grid in double precision).
+static bool j2_row_ok(int v) { return v == 64 || v == 128 || v == 192 || v == 256 || v == 384 || v == 512; }
+// 512-thread rows keep two output rows per workgroup (three would need 82 KB of LDS: one workgroup per CU)
+static int j2_tyo_for(int tpr, int wanted) { return tpr > 384 ? 2 : wanted; }
+
+// fused double sweep: whole (non-distributed) 3-D level whose rows are exactly 64 ... 512 vectors
 // + the odd column; opt out with MG_FUSED_PAIR=0
 template <typename T>
 bool jacobi2_ok(const Geom &g)
@@ -690,7 +697,7 @@ bool jacobi2_ok(const Geom &g)
     static const bool enabled = [] { const char *e = getenv("MG_FUSED_PAIR"); return !(e && e[0] == '0'); }();
     if (!enabled || g.dim != 3 || g.gz0 != 0 || g.gnz != g.nz || g.ny < 3 || g.nz < 3) return false;
     const int v = (g.nx - 1) / V;
-    return (g.nx - 1) % V == 0 && (v == 64 || v == 128 || v == 256);
+    return (g.nx - 1) % V == 0 && j2_row_ok(v);
 }
 
 // the same kernel on the inner planes of a z-slab (mg_solver.cpp: pair_on_slab_t): `g` = the slab's geometry
@@ -704,7 +711,7 @@ bool jacobi2_slab_ok(const Geom &g)
     }();
     if (!enabled || g.dim != 3 || g.ny < 3 || g.nz < 6) return false;
     const int v = (g.nx - 1) / V;
-    return (g.nx - 1) % V == 0 && (v == 64 || v == 128 || v == 256);
+    return (g.nx - 1) % V == 0 && j2_row_ok(v);
 }
 
 template <typename T>
@@ -717,11 +724,13 @@ void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, con
     const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
     // three output rows per workgroup where the correction is not folded in: 5 instead of 4 first-sweep rows
     // per 3 instead of 2 outputs, 167 VGPRs (still 3 workgroups/CU): 0.86 -> 0.79 ms per pair at 513^3
-    static const int tyo = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
+    static const int tyo_env = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
+    const int tyo = j2_tyo_for(tpr, tyo_env);
     const int nby3 = (g.ny + 2) / 3, grid3 = ((nby3 * nbz + 7) / 8) * 8;
 #define MG_J2K(TPR, D, N, Z) \
     do { \
-        if (tyo == 3) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z, 3>), dim3(grid3), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}); \
+        constexpr int TY3 = (TPR > 384) ? 2 : 3; /* never launched with three rows at 512 threads: no such instantiation */ \
+        if (tyo == 3) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z, TY3>), dim3(grid3), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}); \
         else hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
     } while (0)
 #define MG_J2(TPR) \
@@ -730,7 +739,14 @@ void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, con
         else if (damped) { if (nt) MG_J2K(TPR, true, true, false); else MG_J2K(TPR, true, false, false); } \
         else { if (nt) MG_J2K(TPR, false, true, false); else MG_J2K(TPR, false, false, false); } \
     } while (0)
-    if (tpr == 256) MG_J2(256); else if (tpr == 128) MG_J2(128); else MG_J2(64);
+    switch (tpr) {
+    case 512: MG_J2(512); break;
+    case 384: MG_J2(384); break;
+    case 256: MG_J2(256); break;
+    case 192: MG_J2(192); break;
+    case 128: MG_J2(128); break;
+    default: MG_J2(64); break;
+    }
 #undef MG_J2
 #undef MG_J2K
 }
@@ -752,15 +768,23 @@ void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
     const int tpr = (g.nx - 1) / V;
     const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
-    static const int tyo = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
+    static const int tyo_env = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
+    const int tyo = j2_tyo_for(tpr, tyo_env);
     const int nby3 = (g.ny + 2) / 3, grid3 = ((nby3 * nbz + 7) / 8) * 8;
 #define MG_RB2(TPR) \
     do { \
         if (coarse) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, coarse, gc); \
-        else if (tyo == 3) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true, false, 3>), dim3(grid3), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}); \
+        else if (tyo == 3) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true, false, (TPR > 384) ? 2 : 3>), dim3(grid3), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}); \
         else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
     } while (0)
-    if (tpr == 256) MG_RB2(256); else if (tpr == 128) MG_RB2(128); else MG_RB2(64);
+    switch (tpr) {
+    case 512: MG_RB2(512); break;
+    case 384: MG_RB2(384); break;
+    case 256: MG_RB2(256); break;
+    case 192: MG_RB2(192); break;
+    case 128: MG_RB2(128); break;
+    default: MG_RB2(64); break;
+    }
 #undef MG_RB2
 }
 
@@ -791,7 +815,14 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
         if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
         else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
     } while (0)
-    if (tpr == 256) MG_J2C(256); else if (tpr == 128) MG_J2C(128); else MG_J2C(64);
+    switch (tpr) {
+    case 512: MG_J2C(512); break;
+    case 384: MG_J2C(384); break;
+    case 256: MG_J2C(256); break;
+    case 192: MG_J2C(192); break;
+    case 128: MG_J2C(128); break;
+    default: MG_J2C(64); break;
+    }
 #undef MG_J2C
 }
 

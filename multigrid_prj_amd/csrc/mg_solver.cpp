@@ -626,8 +626,11 @@ int Solver::pair_on_slab_t(int level, bool rb)
 
 // corr_level >= 0: x is still missing the coarse-grid correction P u_{corr_level}; the first fused
 // pair applies it on the fly (caller checked can_fold_prolong)
+// e_scratch: the level's E array may be used as scratch (true only inside the V-cycle, where E is idle): the
+// fused pair on a z-slab keeps its boundary planes' first sweep there. The public mg_smooth never passes it, so a
+// caller's E array is left alone (distributed levels then take exchanged single sweeps).
 template <typename T>
-int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero, int corr_level)
+int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero, int corr_level, bool e_scratch)
 {
     Level &L = lv_[level];
     Coef<T> c = coef_of<T>(L);
@@ -637,7 +640,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
     switch (smoother) {
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
-            if (L.dist && overlap_ && d_.cycle == MG_CYCLE_V && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps &&
+            if (L.dist && overlap_ && e_scratch && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps &&
                 !(x_zero && s == 0) && jacobi2_slab_ok<T>(L.g)) {  // E is free in a V-cycle: scratch for the boundary planes' first sweep
                 MG_TRY(pair_on_slab_t<T>(level, false));
                 s++; launches += 5;
@@ -671,7 +674,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
         break;
     case MG_SMOOTH_RBGS:
         for (int s = 0; s < sweeps; s++) {
-            if (L.dist && overlap_ && d_.cycle == MG_CYCLE_V && ax == MG_ARR_U && ar == MG_ARR_RHS &&
+            if (L.dist && overlap_ && e_scratch && ax == MG_ARR_U && ar == MG_ARR_RHS &&
                 jacobi2_slab_ok<T>(L.g) && rb_slab_enabled()) {  // one-pass red-black sweep on the slab's inner planes
                 MG_TRY(pair_on_slab_t<T>(level, true));
                 launches += 5;
@@ -947,7 +950,8 @@ int Solver::coarse_level_t(int l, int ax, int ar)
     const long long pts = (long long)L.g.nx * L.g.ny * L.g.gnz;
     const bool big = pts > 32768;  // e.g. the 17 x 17 x 513 coarsest grid of a semi-coarsened hierarchy
     if (big && d_.coarse_mode == MG_COARSE_FIXED) {
-        MG_TRY(smooth_t<T>(l, d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother, d_.coarse_maxit, ax, ar));
+        MG_TRY(smooth_t<T>(l, d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother, d_.coarse_maxit, ax, ar, false, -1,
+                           d_.cycle == MG_CYCLE_V));
         h_fixed_->iters = d_.coarse_maxit; h_fixed_->flag = 0;
         h_fixed_->relres = 0; h_fixed_->sumsq_rhs = 0; h_fixed_->sumsq_r = 0;  // not evaluated on this path
         MG_HIP(hipMemcpyAsync(d_coarse_, h_fixed_, sizeof(CoarseOut), hipMemcpyHostToDevice, stream_));
@@ -978,7 +982,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
                          resid_restrict_fast_ok<T>(lv_[l].g, lv_[l + 1].g);
     const bool prof = profiling_ && l == 0 && mine;
     if (mine) {
-        MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero));
+        MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero, -1, true));
         if (prof) MG_TRY(prof_begin(l));
         if (!fuse_rr) MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
     }
@@ -1021,7 +1025,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
             if (prof) MG_TRY(prof_end(l, MG_PROF_PROLONG, 1, 1));
         }
     }
-    if (mine) MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS, false, fold ? l + 1 : -1));
+    if (mine) MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS, false, fold ? l + 1 : -1, true));
     return MG_OK;
 }
 

@@ -91,7 +91,7 @@ private:
     // x_zero: the caller knows x == 0 (fresh coarse-level guess): the first Jacobi sweep of a
     // fast-path level then skips reading x (and the caller skips the memset)
     template <typename T> int smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero = false,
-                                       int corr_level = -1);
+                                       int corr_level = -1, bool e_scratch = false);
     template <typename T> bool can_fold_prolong(int level) const;
     template <typename T> int pair_on_slab_t(int level, bool rb);
     template <typename T> bool can_skip_zeroing(int level) const;

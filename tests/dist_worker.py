@@ -41,6 +41,15 @@ def main():
             s.cycle()
         hist, _ = s.solve(0.0, 2)
         u = s.get_solution()
+        if case.get("check_e"):
+            # the public mg_smooth on a distributed level must leave the caller's E array alone (inside the
+            # V-cycle the fused pair uses E as scratch; the API call may not) and still equal the fused result
+            rng = np.random.default_rng(100 + rank)
+            mark = rng.standard_normal(s.level_shape(0)).astype(s.np)
+            s.set_array(capi.ARR_E, 0, mark)
+            s.smooth(0, kw["smoother"], 2, capi.ARR_U, capi.ARR_RHS)
+            assert np.array_equal(s.get_array(capi.ARR_E, 0), mark), "mg_smooth overwrote the E array"
+            u = s.get_solution()
         s.close()
     else:
         from tests.slab_model import SlabVCycle

@@ -181,6 +181,24 @@ def test_hip_distributed_zebra_line_smoother(world, n, levels, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rb", [False, True])
+def test_hip_distributed_public_smooth_leaves_e_alone(rb, tmp_path):
+    """mg_smooth(level, ..., U, RHS) on a distributed level: the caller's E array survives (the V-cycle's
+    fused pair on slabs keeps its boundary planes' first sweep in E; the public call may not), and two
+    exchanged sweeps equal two more sweeps of the single-GPU solver bit for bit."""
+    from multigrid_prj_amd import capi
+    case, desc, b = _case(tmp_path, 129, 3, 1, rb=rb)
+    case["check_e"] = True
+    u, hists, fg = _run_ranks("hip", 2, case, tmp_path)
+    with capi.Solver(capi.make_desc(**desc)) as s:
+        s.set_rhs(b)
+        for _ in range(case["cycles"]):
+            s.cycle()
+        s.smooth(0, desc["smoother"], 2, capi.ARR_U, capi.ARR_RHS)
+        assert np.array_equal(u, s.get_solution())
+
+
+@pytest.mark.gpu
 def test_rccl_transport_selftest():
     """The product transport (RCCL) cannot run two ranks on one GPU; at least exercise
     communicator creation, grouped ncclSend/ncclRecv and ncclAllReduce on this device."""

@@ -180,6 +180,9 @@ VC = [
     dict(dim=3, n=129, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW),
     dict(dim=3, n=257, levels=5, dtype=capi.MG_F64, smoother=capi.SMOOTH_JACOBI, omega=0.8, restriction=capi.RESTRICT_INJECT),
     dict(dim=3, n=257, levels=5, dtype=capi.MG_F32, smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW),
+    # rows of 192 vectors (n = 385 = 3 * 128 + 1): fused pair, residual + restriction and the folded prolongation between 385^3 and 193^3
+    dict(dim=3, n=385, levels=3, dtype=capi.MG_F64, smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW),
+    dict(dim=3, n=385, levels=3, dtype=capi.MG_F64, smoother=capi.SMOOTH_RBGS, omega=1.0, restriction=capi.RESTRICT_FULLW),
     # zebra line smoother along y on an operator whose y-coupling dominates (point smoothers stall at 0.8-0.9)
     dict(dim=3, n=65, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_ZEBRA_Y, omega=1.0, restriction=capi.RESTRICT_FULLW,
          aniso=(1.0, 100.0, 1.0)),
@@ -384,9 +387,13 @@ def test_full_size_jacobi_and_residual_513():
 
 
 @pytest.mark.parametrize("n,dtype,omega", [(129, capi.MG_F64, 6 / 7), (257, capi.MG_F64, 1.0), (257, capi.MG_F32, 6 / 7),
-                                           (513, capi.MG_F64, 6 / 7)])
+                                           (513, capi.MG_F64, 6 / 7),
+                                           # rows of 192 / 384 / 512 vectors: the reference's 385 fixture size in 3-D, 769,
+                                           # and BASELINE config 4's grid in double precision
+                                           (385, capi.MG_F64, 6 / 7), (769, capi.MG_F32, 1.0), (769, capi.MG_F64, 6 / 7),
+                                           (1025, capi.MG_F64, 6 / 7)])
 def test_fused_double_sweep_equals_two_sweeps(n, dtype, omega):
-    """k_jacobi2 (two Jacobi sweeps in one pass, row widths 64 / 128 / 256 vectors) against two
+    """k_jacobi2 (two Jacobi sweeps in one pass, row widths 64 ... 512 vectors) against two
     oracle sweeps, bit for bit, on whole grids including the 513^3 headline size."""
     kw = dict(dim=3, n=n, levels=2, dtype=dtype, length=1.0, alpha=1.0, omega=omega)
     s, ops, do = pair(**kw)
@@ -401,7 +408,7 @@ def test_fused_double_sweep_equals_two_sweeps(n, dtype, omega):
         assert np.array_equal(s.get_array(capi.ARR_U, 0), ops.smooth(0, po.SMOOTH_JACOBI, 3, ref2, b))
 
 
-@pytest.mark.parametrize("n,dtype", [(129, capi.MG_F64), (257, capi.MG_F64), (257, capi.MG_F32), (513, capi.MG_F32)])
+@pytest.mark.parametrize("n,dtype", [(129, capi.MG_F64), (257, capi.MG_F64), (257, capi.MG_F32), (513, capi.MG_F32), (385, capi.MG_F64)])
 def test_fused_red_black_sweep_equals_two_colour_passes(n, dtype):
     """k_jacobi2<RB>: a whole red-black Gauss-Seidel sweep (red half-sweep on plane p, black half-sweep
     on plane p-1 in the same pass) against the oracle's in-place colour sweeps, bit for bit."""
