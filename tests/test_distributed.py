@@ -194,6 +194,7 @@ def test_hip_distributed_public_smooth_leaves_e_alone(rb, tmp_path):
         s.set_rhs(b)
         for _ in range(case["cycles"]):
             s.cycle()
+        s.solve(0.0, 2)   # the worker's history run: two more cycles
         s.smooth(0, desc["smoother"], 2, capi.ARR_U, capi.ARR_RHS)
         assert np.array_equal(u, s.get_solution())
 
