@@ -56,8 +56,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", dest="n", type=int, default=513, help="nodes per side (513 = nominal 512^3)")
     ap.add_argument("--levels", type=int, default=6)
-    ap.add_argument("--smoother", choices=["jacobi", "rbgs", "zebra"], default="jacobi",
-                    help="zebra = zebra line Gauss-Seidel along y (for --aniso-y >> 1)")
+    ap.add_argument("--smoother", choices=["jacobi", "rbgs", "zebra", "zebrax"], default="jacobi",
+                    help="zebra / zebrax = zebra line Gauss-Seidel along y / along x (for --aniso-y / --aniso-x >> 1)")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cycles", type=int, default=8, help="oracle V-cycles timed for cpu_baseline (~1 s each at 513^3)")
@@ -66,6 +66,7 @@ def parse(argv=None):
                          "gloo = rehearsal through host memory, ranks may share a GPU (numbers meaningless)")
     ap.add_argument("--dist-min-n", type=int, default=0, help="mg_desc.dist_min_n (0 = library default)")
     ap.add_argument("--aniso-y", type=float, default=1.0, help="y-coupling multiplier of -(dxx + a dyy + dzz)")
+    ap.add_argument("--aniso-x", type=float, default=1.0, help="x-coupling multiplier of -(a dxx + dyy + dzz)")
     ap.add_argument("--aniso-eps", type=float, default=1.0, help="z-coupling multiplier eps of -(dxx + dyy + eps dzz)")
     ap.add_argument("--semi", type=int, default=0, help="number k of leading x,y-only coarsenings (mg_desc.semi_xy); "
                     "BASELINE config 5: --aniso-eps 0.01 --semi 3 --levels 8 --smoother rbgs")
@@ -148,11 +149,11 @@ def workload_desc(mod, a):
     return mod.make_desc(
         dim=3, n=a.n, levels=a.levels, dtype=mod.MG_F64 if a.dtype == "f64" else mod.MG_F32,
         length=1.0, alpha=1.0, cycle=mod.CYCLE_V,
-        smoother={"jacobi": mod.SMOOTH_JACOBI, "rbgs": mod.SMOOTH_RBGS, "zebra": mod.SMOOTH_ZEBRA_Y}[a.smoother],
+        smoother={"jacobi": mod.SMOOTH_JACOBI, "rbgs": mod.SMOOTH_RBGS, "zebra": mod.SMOOTH_ZEBRA_Y, "zebrax": mod.SMOOTH_ZEBRA_X}[a.smoother],
         omega=6.0 / 7.0 if a.smoother == "jacobi" else 1.0, nu_pre=2, nu_post=2,
         restriction=mod.RESTRICT_FULLW,
         **({} if a.semi else {"coarse_mode": mod.COARSE_TOL, "coarse_maxit": 2000, "coarse_tol": 0.1}),
-        outer_pre_gs=0, dist_min_n=a.dist_min_n, aniso=(1.0, a.aniso_y, a.aniso_eps), semi_xy=a.semi,
+        outer_pre_gs=0, dist_min_n=a.dist_min_n, aniso=(a.aniso_x, a.aniso_y, a.aniso_eps), semi_xy=a.semi,
         **({"coarse_mode": mod.COARSE_FIXED, "coarse_maxit": 20} if a.semi else {}))
 
 
@@ -355,6 +356,7 @@ def main():
                                f"{a.smoother}{' omega=6/7' if a.smoother == 'jacobi' else ''}, full-weighting, "
                                f"{f'eps={a.aniso_eps}, first {a.semi} coarsenings in x,y only, ' if a.semi or a.aniso_eps != 1.0 else ''}"
                                f"{f'y-coupling x{a.aniso_y}, ' if a.aniso_y != 1.0 else ''}"
+                               f"{f'x-coupling x{a.aniso_x}, ' if a.aniso_x != 1.0 else ''}"
                                + (f"20 coarse sweeps, {a.dtype}" if a.semi else
                                   f"coarse {((a.n - 1) >> (a.levels - 1)) + 1}^3 iterated to rel. residual 0.1, {a.dtype}"),
                    "parallelism": (f"z-slab x{world}" + ("" if a.transport == "rccl" else " (gloo rehearsal)")) if world > 1 else "single GPU",

@@ -26,8 +26,11 @@ enum mg_dtype       { MG_F64 = 0, MG_F32 = 1 };
 /* numbering of the first two mirrors -smt 0 / 1 (include/utilities.hpp:9-14) */
 /* MG_SMOOTH_ZEBRA_Y (EXTENSION): zebra line Gauss-Seidel, lines along y solved exactly
  * (Thomas), coloured by the parity of x (+ z): for operators whose y-coupling dominates. The coarsest-grid
- * solver of such a hierarchy smooths with red-black Gauss-Seidel. */
-enum mg_smoother    { MG_SMOOTH_GS_LEX = 0, MG_SMOOTH_JACOBI = 1, MG_SMOOTH_RBGS = 2, MG_SMOOTH_ZEBRA_Y = 3 };
+ * solver of such a hierarchy smooths with red-black Gauss-Seidel.
+ * MG_SMOOTH_ZEBRA_X: the same with lines along x (the fast axis), coloured by the parity of y (+ z): for a dominant
+ * x-coupling (aniso[0] >> 1). */
+enum mg_smoother    { MG_SMOOTH_GS_LEX = 0, MG_SMOOTH_JACOBI = 1, MG_SMOOTH_RBGS = 2, MG_SMOOTH_ZEBRA_Y = 3,
+                      MG_SMOOTH_ZEBRA_X = 4 };
 enum mg_cycle_kind  { MG_CYCLE_SAWTOOTH = 0,   /* reference cycle, multigrid.hpp:126-145 */
                       MG_CYCLE_V        = 1 }; /* standard V(nu_pre,nu_post), extension  */
 enum mg_restriction { MG_RESTRICT_INJECT = 0,  /* reference: aliasing via mask()         */

@@ -82,8 +82,8 @@ int mg_zero_array(mg_handle h, int which, int level);
  *   MG_SMOOTH_JACOBI -> Jacobi_iteration::apply_iteration_to_vec  solvers.hpp:64-83
  *   MG_SMOOTH_GS_LEX -> Gauss_Seidel_iteration::…                 solvers.hpp:33-48
  *   MG_SMOOTH_RBGS   -> red-black GS (extension)
- *   MG_SMOOTH_ZEBRA_Y -> zebra line GS along y (extension; only on a handle created with that smoother,
- *                        which tabulates the line factors per level)
+ *   MG_SMOOTH_ZEBRA_Y / MG_SMOOTH_ZEBRA_X -> zebra line GS along y / along x (extension; only on a handle created
+ *                        with that smoother, which tabulates the line factors per level)
  * arr_x / arr_rhs name which device arrays play x and rhs. */
 int mg_smooth(mg_handle h, int level, int smoother, int sweeps, int arr_x, int arr_rhs);
 

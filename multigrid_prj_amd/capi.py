@@ -12,7 +12,7 @@ import numpy as np
 from . import build as _build
 
 MG_F64, MG_F32 = 0, 1
-SMOOTH_GS_LEX, SMOOTH_JACOBI, SMOOTH_RBGS, SMOOTH_ZEBRA_Y = 0, 1, 2, 3
+SMOOTH_GS_LEX, SMOOTH_JACOBI, SMOOTH_RBGS, SMOOTH_ZEBRA_Y, SMOOTH_ZEBRA_X = 0, 1, 2, 3, 4
 CYCLE_SAWTOOTH, CYCLE_V = 0, 1
 RESTRICT_INJECT, RESTRICT_FULLW = 0, 1
 COARSE_TOL, COARSE_FIXED = 0, 1

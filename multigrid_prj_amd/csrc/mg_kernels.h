@@ -36,11 +36,16 @@ template <typename T> bool jacobi2_corr_ok(const Geom &gf, const Geom &gc);
 template <typename T>
 void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u,
                          const T *coarse, const T *rhs, T *out);
-// zebra line Gauss-Seidel along y: one colour pass; cp_den = the 2*ny factors of zebra_y_factors (device)
+// zebra line Gauss-Seidel along y: one colour pass; cp_den = the 2*ny factors of zebra_line_factors(cy, cd, ny) (device)
 template <typename T>
 void launch_zebra_y(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u, const T *rhs, T *dp,
                     const T *cp_den);
-template <typename T> void zebra_y_factors(const Coef<T> &c, int ny, T *out);
+// the same with lines along x (k_zebra_x): cp_den = the 2*nx factors of zebra_line_factors(cx, cd, nx)
+template <typename T>
+void launch_zebra_x(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u, const T *rhs, T *dp,
+                    const T *cp_den);
+// elimination factors cp(j), den(j) of a line with off-diagonal cl and diagonal cd: out = 2 * n values (host)
+template <typename T> void zebra_line_factors(T cl, T cd, int n, T *out);
 // one whole red-black sweep in one pass (same gate as the fused double Jacobi sweep)
 template <typename T> bool rb_fused_ok(const Geom &g);
 template <typename T>

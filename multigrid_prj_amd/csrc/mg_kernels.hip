@@ -1173,6 +1173,112 @@ __global__ __launch_bounds__(256) void k_zebra_y(Geom g, Coef<T> c, int colour, 
     u[base] = dp[dbase];
 }
 
+// ---------------------------------------------------------------- zebra line Gauss-Seidel along x
+// One colour pass, lines along the FAST axis (EXTENSION), coloured by the parity of y (+ z). A thread
+// marching along its own line would use 8 bytes of every 128-byte line it touches, so a workgroup of ZXT threads takes
+// ZXT lines of the active colour and walks them in chunks of XC = 128 B / sizeof(T) columns:
+//   (A) all threads together evaluate R = b - S on the ZXT x XC tile -- 16 (32) consecutive lanes per line segment, so
+//       every access is a whole aligned 128-byte line -- into LDS;
+//   (B) thread t runs the elimination recurrence of line t over the chunk's columns out of LDS (rows padded to an odd
+//       stride: conflict-free), carrying dp(x-1) in a register from chunk to chunk;
+//   (C) the tile goes to the dp scratch array, coalesced again.
+// The back substitution walks the chunks in reverse the same way. Per line the operations and their order are those of
+// the CPU restatement's sequential Thomas solve => same bits; lines never cross a z-slab.
+constexpr int ZXT = 256;
+
+template <typename T, int DIM>
+__global__ __launch_bounds__(ZXT) void k_zebra_x(Geom g, Coef<T> c, int colour, T *__restrict__ u, const T *__restrict__ rhs,
+                                                 T *__restrict__ dp, const T *__restrict__ cp, const T *__restrict__ den,
+                                                 int lpp, int nlines)
+{
+    constexpr int XC = 128 / (int)sizeof(T), LP = XC + 1;
+    __shared__ T tile[ZXT][LP];
+    __shared__ long long lbase[ZXT];
+    __shared__ int lflag[ZXT];  // 0: no such line, 1: interior line, 2: line inside the boundary (identity rows)
+    const int t = threadIdx.x;
+    {
+        const int L = blockIdx.x * ZXT + t;  // line slot: z = L / lpp, y = 2 (L % lpp) + parity
+        const int z = L / lpp, k = L - z * lpp;
+        const int gz = (DIM == 3) ? g.gz0 + z : 0;
+        const int y = 2 * k + ((colour + gz) & 1);
+        const bool active = L < nlines && y < g.ny;
+        const bool bnd = (y == 0) || (y == g.ny - 1) || (DIM == 3 && (gz == 0 || gz == g.gnz - 1));
+        lbase[t] = active ? (long long)z * g.plane + (long long)y * g.pitch : 0;
+        lflag[t] = active ? (bnd ? 2 : 1) : 0;
+    }
+    __syncthreads();
+    const int nx = g.nx, nch = (nx + XC - 1) / XC;
+    const int myflag = lflag[t];
+    T carry = 0;  // dp(x-1) of the thread's own line
+    for (int ch = 0; ch < nch; ch++) {
+        const int x0 = ch * XC;
+        for (int p = t; p < ZXT * XC; p += ZXT) {  // (A)
+            const int ll = p / XC, col = p % XC, x = x0 + col;
+            const int fl = lflag[ll];
+            T R = 0;
+            if (fl && x < nx) {
+                const long long idx = lbase[ll] + x;
+                R = rhs[idx];
+                if (fl == 1 && x > 0 && x < nx - 1) {
+                    T S = 0;
+                    if (DIM == 3) S += c.cz * u[idx - g.plane];
+                    S += c.cy * u[idx - g.pitch];
+                    S += c.cy * u[idx + g.pitch];
+                    if (DIM == 3) S += c.cz * u[idx + g.plane];
+                    R = R - S;
+                }
+            }
+            tile[ll][col] = R;
+        }
+        __syncthreads();
+        if (myflag == 1) {  // (B) dp(0) = b(0); dp(x) = (R(x) - cx dp(x-1)) / den(x); the last column keeps b(nx-1)
+#pragma unroll 4
+            for (int col = 0; col < XC; col++) {
+                const int x = x0 + col;
+                if (x >= nx) break;
+                const T r = tile[t][col];
+                if (x == 0 || x == nx - 1) carry = r;
+                else carry = (r - c.cx * carry) / den[x];
+                tile[t][col] = carry;
+            }
+        }
+        __syncthreads();
+        for (int p = t; p < ZXT * XC; p += ZXT) {  // (C)
+            const int ll = p / XC, col = p % XC, x = x0 + col;
+            if (lflag[ll] && x < nx) dp[lbase[ll] + x] = tile[ll][col];
+        }
+        __syncthreads();
+    }
+    // back substitution: u(nx-1) = b(nx-1); u(x) = dp(x) - cp(x) u(x+1); u(0) = dp(0)
+    for (int ch = nch - 1; ch >= 0; ch--) {
+        const int x0 = ch * XC;
+        for (int p = t; p < ZXT * XC; p += ZXT) {
+            const int ll = p / XC, col = p % XC, x = x0 + col;
+            T v = 0;
+            if (lflag[ll] && x < nx) v = dp[lbase[ll] + x];
+            tile[ll][col] = v;
+        }
+        __syncthreads();
+        if (myflag == 1) {
+#pragma unroll 4
+            for (int col = XC - 1; col >= 0; col--) {
+                const int x = x0 + col;
+                if (x >= nx) continue;
+                const T d = tile[t][col];
+                if (x == 0 || x == nx - 1) carry = d;
+                else carry = d - cp[x] * carry;
+                tile[t][col] = carry;
+            }
+        }
+        __syncthreads();
+        for (int p = t; p < ZXT * XC; p += ZXT) {
+            const int ll = p / XC, col = p % XC, x = x0 + col;
+            if (lflag[ll] && x < nx) u[lbase[ll] + x] = tile[ll][col];
+        }
+        __syncthreads();
+    }
+}
+
 inline dim3 grid_for(int nx, int ny, int nz)
 {
     return dim3((nx + BX - 1) / BX, (ny + BY - 1) / BY, nz);
@@ -1246,14 +1352,25 @@ void launch_zebra_y(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, 
     else hipLaunchKernelGGL((k_zebra_y<T, 2>), gr, bl, 0, s, g, c, colour, u, rhs, dp, cp_den, cp_den + g.ny);
 }
 
-// cp(j), den(j) of the line solve, computed in T with the same two operations per row as the CPU restatement; out: 2 * ny values
 template <typename T>
-void zebra_y_factors(const Coef<T> &c, int ny, T *out)
+void launch_zebra_x(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u, const T *rhs, T *dp,
+                    const T *cp_den)
 {
-    T *cp = out, *den = out + ny;
+    const int lpp = (g.ny + 1) / 2, nlines = lpp * g.nz;   // line slots of one colour: (z, k) -> y = 2k + parity
+    dim3 bl(ZXT), gr((nlines + ZXT - 1) / ZXT);
+    if (g.dim == 3) hipLaunchKernelGGL((k_zebra_x<T, 3>), gr, bl, 0, s, g, c, colour, u, rhs, dp, cp_den, cp_den + g.nx, lpp, nlines);
+    else hipLaunchKernelGGL((k_zebra_x<T, 2>), gr, bl, 0, s, g, c, colour, u, rhs, dp, cp_den, cp_den + g.nx, lpp, nlines);
+}
+
+// cp(j), den(j) of the line solve (cl = the off-diagonal along the line), computed in T with the same two operations
+// per row as the CPU restatement; out: 2 * n values
+template <typename T>
+void zebra_line_factors(T cl, T cd, int n, T *out)
+{
+    T *cp = out, *den = out + n;
     cp[0] = 0; den[0] = 1;
-    for (int j = 1; j < ny - 1; j++) { den[j] = c.cd - c.cy * cp[j - 1]; cp[j] = c.cy / den[j]; }
-    cp[ny - 1] = 0; den[ny - 1] = 1;
+    for (int j = 1; j < n - 1; j++) { den[j] = cd - cl * cp[j - 1]; cp[j] = cl / den[j]; }
+    cp[n - 1] = 0; den[n - 1] = 1;
 }
 
 template <typename T>
@@ -1449,7 +1566,8 @@ void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega
                                         const T *);                                                \
     template void launch_gs_lex<T>(hipStream_t, const Geom &, const Coef<T> &, int, T *, const T *); \
     template void launch_zebra_y<T>(hipStream_t, const Geom &, const Coef<T> &, int, T *, const T *, T *, const T *); \
-    template void zebra_y_factors<T>(const Coef<T> &, int, T *); \
+    template void launch_zebra_x<T>(hipStream_t, const Geom &, const Coef<T> &, int, T *, const T *, T *, const T *); \
+    template void zebra_line_factors<T>(T, T, int, T *); \
     template void launch_residual<T>(hipStream_t, const Geom &, const Coef<T> &, const T *,        \
                                      const T *, T *, double *, double *);                          \
     template void launch_sumsq<T>(hipStream_t, const Geom &, const T *, double *, double *);       \

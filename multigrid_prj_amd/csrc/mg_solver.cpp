@@ -38,7 +38,7 @@ int validate_desc(const mg_desc *d, std::string *why)
     if ((d->n - 1) % step != 0) return fail("n-1 must be a multiple of 2^(levels-1)");
     if ((d->n - 1) / step + 1 < 3) return fail("coarsest grid would have fewer than 3 nodes per side");
     if (d->dtype != MG_F64 && d->dtype != MG_F32) return fail("dtype must be MG_F64 or MG_F32");
-    if (d->smoother < MG_SMOOTH_GS_LEX || d->smoother > MG_SMOOTH_ZEBRA_Y) return fail("unknown smoother");
+    if (d->smoother < MG_SMOOTH_GS_LEX || d->smoother > MG_SMOOTH_ZEBRA_X) return fail("unknown smoother");
     if (d->cycle != MG_CYCLE_SAWTOOTH && d->cycle != MG_CYCLE_V) return fail("unknown cycle kind");
     if (d->restriction != MG_RESTRICT_INJECT && d->restriction != MG_RESTRICT_FULLW) return fail("unknown restriction");
     if (d->coarse_mode != MG_COARSE_TOL && d->coarse_mode != MG_COARSE_FIXED) return fail("unknown coarse mode");
@@ -51,6 +51,10 @@ int validate_desc(const mg_desc *d, std::string *why)
     if (d->semi_xy && d->dim != 3) return fail("semi-coarsening (semi_xy) needs dim == 3");
     return MG_OK;
 }
+
+static bool is_zebra(int smoother) { return smoother == MG_SMOOTH_ZEBRA_Y || smoother == MG_SMOOTH_ZEBRA_X; }
+// the coarsest-grid solver of a zebra hierarchy smooths with red-black Gauss-Seidel (mg_desc.h)
+static int coarse_smoother_of(int smoother) { return is_zebra(smoother) ? MG_SMOOTH_RBGS : smoother; }
 
 int level_n(const mg_desc &d, int level)
 {
@@ -265,16 +269,19 @@ int Solver::init()
             MG_HIP(hipMemsetAsync(L.base[a], 0, nbytes, stream_));
             bytes_ += nbytes;
         }
-        if (d_.smoother == MG_SMOOTH_ZEBRA_Y) {
-            const size_t nb = 2 * (size_t)L.g.ny * esize();
+        if (is_zebra(d_.smoother)) {  // elimination factors of the line solve: along y (cy, ny) or along x (cx, nx)
+            const bool alongx = d_.smoother == MG_SMOOTH_ZEBRA_X;
+            const int nl = alongx ? L.g.nx : L.g.ny;
+            const double cl = alongx ? L.coef[0] : L.coef[1];
+            const size_t nb = 2 * (size_t)nl * esize();
             MG_HIP(hipMalloc(&L.zebra, nb));
             if (d_.dtype == MG_F64) {
-                std::vector<double> f(2 * (size_t)L.g.ny);
-                zebra_y_factors<double>(make_coef<double>(L.coef[0], L.coef[1], L.coef[2], L.coef[3]), L.g.ny, f.data());
+                std::vector<double> f(2 * (size_t)nl);
+                zebra_line_factors<double>(cl, L.coef[3], nl, f.data());
                 MG_HIP(hipMemcpy(L.zebra, f.data(), nb, hipMemcpyHostToDevice));
             } else {
-                std::vector<float> f(2 * (size_t)L.g.ny);
-                zebra_y_factors<float>(make_coef<float>(L.coef[0], L.coef[1], L.coef[2], L.coef[3]), L.g.ny, f.data());
+                std::vector<float> f(2 * (size_t)nl);
+                zebra_line_factors<float>((float)cl, (float)L.coef[3], nl, f.data());
                 MG_HIP(hipMemcpy(L.zebra, f.data(), nb, hipMemcpyHostToDevice));
             }
             bytes_ += nb;
@@ -706,16 +713,21 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
         }
         break;
     case MG_SMOOTH_ZEBRA_Y:
-        if (sweeps > 0 && !L.zebra) {
-            set_last_error("zebra line smoother: the handle was not created with MG_SMOOTH_ZEBRA_Y");
+    case MG_SMOOTH_ZEBRA_X:
+        if (sweeps > 0 && (!L.zebra || smoother != d_.smoother)) {
+            set_last_error("zebra line smoother: the handle was not created with this smoother (its line factors are tabulated at creation)");
             return MG_ERR_BAD_ARG;
         }
         launches += 2 * sweeps;
         for (int s = 0; s < sweeps; s++)
             for (int colour = 0; colour < 2; colour++) {
                 MG_TRY(exchange(ax, level));  // the other colour's ghost planes (z-slabs; lines run along y)
-                launch_zebra_y<T>(stream_, L.g, c, colour, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
-                                  static_cast<const T *>(L.zebra));
+                if (smoother == MG_SMOOTH_ZEBRA_X)
+                    launch_zebra_x<T>(stream_, L.g, c, colour, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
+                                      static_cast<const T *>(L.zebra));
+                else
+                    launch_zebra_y<T>(stream_, L.g, c, colour, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
+                                      static_cast<const T *>(L.zebra));
             }
         break;
     default:
@@ -735,7 +747,7 @@ int Solver::smooth(int level, int smoother, int sweeps, int arr_x, int arr_rhs)
 {
     if (!check_arr(arr_x, level, "mg_smooth") || !check_arr(arr_rhs, level, "mg_smooth")) return MG_ERR_BAD_ARG;
     if (arr_x == MG_ARR_TMP || arr_rhs == MG_ARR_TMP || arr_x == arr_rhs || sweeps < 0 ||
-        smoother < MG_SMOOTH_GS_LEX || smoother > MG_SMOOTH_ZEBRA_Y) {
+        smoother < MG_SMOOTH_GS_LEX || smoother > MG_SMOOTH_ZEBRA_X) {
         set_last_error("mg_smooth: bad array / smoother / sweeps");
         return MG_ERR_BAD_ARG;
     }
@@ -889,7 +901,7 @@ template <typename T>
 int Solver::coarse_t(int level, int ax, int ar)
 {
     // the coarsest-grid solver of a zebra hierarchy smooths with red-black Gauss-Seidel (mg_desc.h)
-    const int sm = d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother;
+    const int sm = coarse_smoother_of(d_.smoother);
     if (lock_iters_ >= 0) return coarse_ex_t<T>(level, ax, ar, sm, lock_iters_, d_.coarse_tol, 1);
     return coarse_ex_t<T>(level, ax, ar, sm, d_.coarse_maxit, d_.coarse_tol,
                           d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0);
@@ -897,7 +909,7 @@ int Solver::coarse_t(int level, int ax, int ar)
 
 int Solver::coarse_solve(int level, int arr_x, int arr_rhs, mg_cycle_stats *st)
 {
-    return coarse_solve_ex(level, arr_x, arr_rhs, d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother,
+    return coarse_solve_ex(level, arr_x, arr_rhs, coarse_smoother_of(d_.smoother),
                            d_.coarse_maxit, d_.coarse_tol, d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0, st);
 }
 
@@ -935,7 +947,7 @@ int Solver::coarse_full_t()
     Level &L = lv_[T_];
     MG_HIP(hipMemsetAsync(full_[1], 0, (size_t)(gfull_.nz + 2) * (size_t)gfull_.plane * esize(), stream_));
     launch_coarse_solve<T>(stream_, gfull_, coef_of<T>(L), (T)d_.omega,
-                           d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother, fullptr<T>(1), fullptr<T>(2),
+                           coarse_smoother_of(d_.smoother), fullptr<T>(1), fullptr<T>(2),
                            fullptr<T>(0), lock_iters_ >= 0 ? lock_iters_ : d_.coarse_maxit, d_.coarse_tol,
                            (lock_iters_ >= 0 || d_.coarse_mode == MG_COARSE_FIXED) ? 1 : 0, d_coarse_);
     MG_HIP(hipGetLastError());
@@ -950,7 +962,7 @@ int Solver::coarse_level_t(int l, int ax, int ar)
     const long long pts = (long long)L.g.nx * L.g.ny * L.g.gnz;
     const bool big = pts > 32768;  // e.g. the 17 x 17 x 513 coarsest grid of a semi-coarsened hierarchy
     if (big && d_.coarse_mode == MG_COARSE_FIXED) {
-        MG_TRY(smooth_t<T>(l, d_.smoother == MG_SMOOTH_ZEBRA_Y ? MG_SMOOTH_RBGS : d_.smoother, d_.coarse_maxit, ax, ar, false, -1,
+        MG_TRY(smooth_t<T>(l, coarse_smoother_of(d_.smoother), d_.coarse_maxit, ax, ar, false, -1,
                            d_.cycle == MG_CYCLE_V));
         h_fixed_->iters = d_.coarse_maxit; h_fixed_->flag = 0;
         h_fixed_->relres = 0; h_fixed_->sumsq_rhs = 0; h_fixed_->sumsq_r = 0;  // not evaluated on this path

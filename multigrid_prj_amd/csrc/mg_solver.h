@@ -41,7 +41,7 @@ struct Level {
     double coef[4] = {};
     bool present = true;         // false: level not held by this rank (gathered on rank 0)
     bool dist = false;           // true: z-slab of a level distributed over all ranks
-    void *zebra = nullptr;       // MG_SMOOTH_ZEBRA_Y: cp(j), den(j) of the line solve (2 * ny values, device)
+    void *zebra = nullptr;       // MG_SMOOTH_ZEBRA_Y / _X: cp(j), den(j) of the line solve (2 * ny or 2 * nx values, device)
 };
 
 class Solver {

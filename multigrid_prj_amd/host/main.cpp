@@ -19,7 +19,7 @@ int main(int argc, char **argv)
 
     mg_desc d;
     // -smt 2 ("BiCGSTAB") runs the Jacobi cycle in the reference too (main.cpp:103-106)
-    const int smoother = opt.zebra ? MG_SMOOTH_ZEBRA_Y
+    const int smoother = opt.zebrax ? MG_SMOOTH_ZEBRA_X : opt.zebra ? MG_SMOOTH_ZEBRA_Y
                                    : opt.rbgs ? MG_SMOOTH_RBGS : (opt.smoother == Gauss_Siedel ? MG_SMOOTH_GS_LEX : MG_SMOOTH_JACOBI);
     mg_desc_reference_defaults(&d, static_cast<int>(opt.N), opt.level, opt.width, opt.alpha, smoother);
     d.dim = opt.dim;
@@ -36,7 +36,7 @@ int main(int argc, char **argv)
     if (opt.full_weighting) d.restriction = MG_RESTRICT_FULLW;
     if (opt.coarse_fixed >= 0) { d.coarse_mode = MG_COARSE_FIXED; d.coarse_maxit = opt.coarse_fixed; }
     if (opt.dim == 3) d.outer_pre_gs = 0;
-    d.aniso[2] = opt.eps_z;
+    d.aniso[0] = opt.aniso_x; d.aniso[1] = opt.aniso_y; d.aniso[2] = opt.eps_z;
     d.semi_xy = opt.semi;
 
     // right-hand side: g on the boundary, f inside (DataVector)

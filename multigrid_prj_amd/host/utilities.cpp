@@ -35,7 +35,7 @@ void usage()
               << "  -smt, you can choose your favourite smoother" << std::endl
               << "  --help, Display this help message" << std::endl
               << "MI355X extensions:" << std::endl
-              << "  -dim 2|3, -cycle saw|v, -omega W, -nu1 K, -nu2 K, -rbgs, -zebra, -fw, -coarse_fixed K, -fp32, -maxit K, -cold, -eps E, -semi K" << std::endl;
+              << "  -dim 2|3, -cycle saw|v, -omega W, -nu1 K, -nu2 K, -rbgs, -zebra, -zebrax, -anisox A, -anisoy A, -fw, -coarse_fixed K, -fp32, -maxit K, -cold, -eps E, -semi K" << std::endl;
 }
 
 }  // namespace
@@ -99,6 +99,9 @@ void Utils::parse_command_line(int argc, char **argv, Options &o)
         else if (a == "-semi" && has_value) { o.semi = std::atoi(argv[i + 1]); }
         else if (a == "-rbgs") { o.rbgs = true; }
         else if (a == "-zebra") { o.zebra = true; }  // zebra line Gauss-Seidel along y
+        else if (a == "-zebrax") { o.zebrax = true; }  // ... along x
+        else if (a == "-anisox" && has_value) { o.aniso_x = std::atof(argv[i + 1]); }
+        else if (a == "-anisoy" && has_value) { o.aniso_y = std::atof(argv[i + 1]); }
         else if (a == "-fw") { o.full_weighting = true; }
         else if (a == "-fp32") { o.fp32 = true; }
         else if (a == "-cold") { o.cold = true; }

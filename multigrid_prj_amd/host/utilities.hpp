@@ -28,11 +28,11 @@ struct Options {
     int level = DEFAULT_LEVEL;
     int test = DEFAULT_TEST;
     SMOOTHERS smoother = DEFAULT_METHOD;
-    // extensions (absent from the reference): -dim 3, -cycle v, -omega, -nu1, -nu2, -rbgs, -zebra,
+    // extensions (absent from the reference): -dim 3, -cycle v, -omega, -nu1, -nu2, -rbgs, -zebra, -zebrax (line Gauss-Seidel along y / x), -anisox A, -anisoy A (coupling multipliers),
     // -fw, -coarse_fixed K, -fp32, -maxit, -cold (no warm-up cycle before the solve timer), -eps E (z-coupling multiplier), -semi K (first K coarsenings in x,y only)
     int dim = 2;
-    bool vcycle = false, rbgs = false, zebra = false, full_weighting = false, fp32 = false, cold = false;
-    double omega = 1.0, eps_z = 1.0;
+    bool vcycle = false, rbgs = false, zebra = false, full_weighting = false, fp32 = false, cold = false, zebrax = false;
+    double omega = 1.0, eps_z = 1.0, aniso_x = 1.0, aniso_y = 1.0;
     int semi = 0;
     int nu1 = 2, nu2 = -1, coarse_fixed = -1, maxit = 1000;
 };

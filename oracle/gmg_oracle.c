@@ -33,7 +33,7 @@ int orc_validate(const mg_desc *d)
     if ((d->n - 1) % step != 0) return -5;
     if ((d->n - 1) / step + 1 < 3) return -6;
     if (d->dtype != MG_F64 && d->dtype != MG_F32) return -7;
-    if (d->smoother < MG_SMOOTH_GS_LEX || d->smoother > MG_SMOOTH_ZEBRA_Y) return -8;
+    if (d->smoother < MG_SMOOTH_GS_LEX || d->smoother > MG_SMOOTH_ZEBRA_X) return -8;
     if (d->cycle != MG_CYCLE_SAWTOOTH && d->cycle != MG_CYCLE_V) return -9;
     if (!(d->length > 0) || !(d->alpha > 0)) return -10;
     if (d->coarse_maxit < 0 || d->nu_pre < 0 || d->nu_post < 0 || d->outer_pre_gs < 0) return -11;

@@ -52,7 +52,7 @@ def _run_ranks(mode, world, case, tmp_path, timeout=600):
     return np.concatenate([p["u"] for p in parts], axis=0), [p["hist"] for p in parts], int(parts[0]["fg"])
 
 
-def _case(tmp_path, n, levels, restriction, cycles=2, semi=0, zebra=False, rb=False, dtype=0):
+def _case(tmp_path, n, levels, restriction, cycles=2, semi=0, zebra=False, rb=False, dtype=0, semi_zebra=False):
     desc = dict(dim=3, n=n, levels=levels, dtype=dtype, length=1.0, alpha=1.0, cycle=1, smoother=1, omega=6 / 7,
                 nu_pre=2, nu_post=2, restriction=restriction, coarse_mode=1, coarse_maxit=20, outer_pre_gs=0,
                 dist_min_n=33)
@@ -60,8 +60,12 @@ def _case(tmp_path, n, levels, restriction, cycles=2, semi=0, zebra=False, rb=Fa
         desc.update(semi_xy=1, aniso=(1.0, 1.0, 0.25), omega=0.8, coarse_maxit=80)
     if rb:
         desc.update(smoother=2, omega=1.0)
-    if zebra:  # strong y-coupling, zebra lines along y (they never cross the z-slabs)
+    if zebra == "x":  # strong x-coupling, zebra lines along x
+        desc.update(smoother=4, omega=1.0, aniso=(50.0, 1.0, 1.0))
+    elif zebra:  # strong y-coupling, zebra lines along y (they never cross the z-slabs)
         desc.update(smoother=3, omega=1.0, aniso=(1.0, 50.0, 1.0))
+    if semi_zebra:  # weak z-coupling AND dominant y-coupling: two semi-coarsenings + zebra lines along y
+        desc.update(smoother=3, omega=1.0, semi_xy=2, aniso=(1.0, 30.0, 0.05), coarse_maxit=40)
     b = po.fill_rhs_3d(n, 1.0, 1.0, 1)
     if dtype == 1:
         b = b.astype(np.float32)
@@ -162,10 +166,11 @@ def test_hip_distributed_red_black(world, n, levels, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,n,levels", [(2, 65, 3), (3, 65, 2)])
-def test_hip_distributed_zebra_line_smoother(world, n, levels, tmp_path):
-    """Zebra lines run along y and the slabs cut z: k ranks equal one rank (and the oracle) bit for bit."""
+@pytest.mark.parametrize("direction", ["y", "x"])
+def test_hip_distributed_zebra_line_smoother(world, n, levels, direction, tmp_path):
+    """Zebra lines run along y (or x) and the slabs cut z: k ranks equal one rank (and the oracle) bit for bit."""
     from multigrid_prj_amd import capi
-    case, desc, b = _case(tmp_path, n, levels, 1, zebra=True)
+    case, desc, b = _case(tmp_path, n, levels, 1, zebra=True if direction == "y" else "x")
     u, hists, fg = _run_ranks("hip", world, case, tmp_path)
     with capi.Solver(capi.make_desc(**desc)) as s:
         s.set_rhs(b)
@@ -178,6 +183,32 @@ def test_hip_distributed_zebra_line_smoother(world, n, levels, tmp_path):
     assert np.array_equal(u, u_ref)
     # (2 levels: the 33^3 coarse grid only gets 20 red-black sweeps, so it is far from solved)
     assert h1[-1] < (0.2 if levels >= 3 else 0.7) * h1[-2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_hip_semi_coarsening_plus_zebra_lines_on_1_2_3_ranks(world, tmp_path):
+    """BASELINE config 5 as worded, in miniature (n = 129): semi-coarsening for the weak z-coupling AND zebra line
+    Gauss-Seidel along the dominant y direction. The slabs cut z, the lines run along y and the semi-coarsened levels
+    share their slabs, so k ranks equal one rank equal the oracle bit for bit; the combination converges like multigrid
+    where each ingredient alone stalls (tests/test_oracle_vs_reference.py has the four factors)."""
+    from multigrid_prj_amd import capi
+    case, desc, b = _case(tmp_path, 129, 5, 1, semi_zebra=True)
+    u_ref, h_ref = _oracle(desc, b, case["cycles"])
+    if world == 1:
+        with capi.Solver(capi.make_desc(**desc)) as s:
+            s.set_rhs(b)
+            for _ in range(case["cycles"]):
+                s.cycle()
+            h1, _ = s.solve(0.0, 2)
+            u = s.get_solution()
+    else:
+        u, hists, fg = _run_ranks("hip", world, case, tmp_path)
+        assert fg >= 3      # levels 0..2 keep the finest z resolution and the same slabs
+        h1 = hists[0]
+    assert np.array_equal(u, u_ref)
+    np.testing.assert_allclose(h1, h_ref, rtol=1e-11)
+    assert h1[-1] < 0.1 * h1[-2]
 
 
 @pytest.mark.gpu

@@ -190,6 +190,19 @@ VC = [
          aniso=(1.0, 100.0, 1.0)),
     dict(dim=3, n=65, levels=4, dtype=capi.MG_F32, smoother=capi.SMOOTH_ZEBRA_Y, omega=1.0, restriction=capi.RESTRICT_FULLW,
          aniso=(1.0, 30.0, 1.0)),
+    # zebra lines along x (the fast axis: LDS-staged chunks) on a dominant x-coupling
+    dict(dim=3, n=65, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_ZEBRA_X, omega=1.0, restriction=capi.RESTRICT_FULLW,
+         aniso=(100.0, 1.0, 1.0)),
+    dict(dim=2, n=129, levels=5, dtype=capi.MG_F64, smoother=capi.SMOOTH_ZEBRA_X, omega=1.0, restriction=capi.RESTRICT_FULLW,
+         aniso=(100.0, 1.0, 1.0)),
+    dict(dim=3, n=129, levels=5, dtype=capi.MG_F32, smoother=capi.SMOOTH_ZEBRA_X, omega=1.0, restriction=capi.RESTRICT_FULLW,
+         semi_xy=2, aniso=(30.0, 1.0, 0.05)),
+    # BASELINE config 5 as worded -- semi-coarsening + a line smoother in the strong direction: weak z-coupling (eps = 0.05,
+    # log4(1/eps) ~ 2 semi-coarsenings) and a dominant y-coupling (zebra lines along y); neither ingredient alone converges
+    dict(dim=3, n=65, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_ZEBRA_Y, omega=1.0, restriction=capi.RESTRICT_FULLW,
+         semi_xy=2, aniso=(1.0, 30.0, 0.05)),
+    dict(dim=3, n=129, levels=5, dtype=capi.MG_F32, smoother=capi.SMOOTH_ZEBRA_Y, omega=1.0, restriction=capi.RESTRICT_FULLW,
+         semi_xy=2, aniso=(1.0, 30.0, 0.05)),
     # red-black with the fused one-pass sweep and the prolongation folded into the first post-sweep
     dict(dim=3, n=129, levels=4, dtype=capi.MG_F64, smoother=capi.SMOOTH_RBGS, omega=1.0, restriction=capi.RESTRICT_FULLW),
     dict(dim=3, n=257, levels=5, dtype=capi.MG_F32, smoother=capi.SMOOTH_RBGS, omega=1.0, restriction=capi.RESTRICT_FULLW),
@@ -431,28 +444,35 @@ def test_fused_red_black_sweep_equals_two_colour_passes(n, dtype):
     dict(dim=3, n=33, dtype=capi.MG_F64, aniso=(1.0, 1.0, 1.0)),
     dict(dim=3, n=65, dtype=capi.MG_F32, aniso=(1.0, 30.0, 1.0)),
     dict(dim=3, n=129, dtype=capi.MG_F64, aniso=(1.0, 100.0, 1.0)),
+    dict(dim=2, n=49, dtype=capi.MG_F32, aniso=(1.0, 20.0, 1.0)),
+    dict(dim=3, n=21, dtype=capi.MG_F64, aniso=(1.0, 5.0, 2.0)),
 ], ids=lambda c: f"{c['dim']}d-n{c['n']}-t{c['dtype']}")
-def test_zebra_line_smoother_bit_exact(case):
-    """Zebra line Gauss-Seidel along y: each colour pass solves every line of that colour
-    with the Thomas algorithm, one thread per line; same recurrences as the oracle => same bits."""
-    kw = dict(levels=2, length=1.0, alpha=1.0, omega=1.0, smoother=capi.SMOOTH_ZEBRA_Y, **case)
+@pytest.mark.parametrize("zsm", [capi.SMOOTH_ZEBRA_Y, capi.SMOOTH_ZEBRA_X], ids=["y-lines", "x-lines"])
+def test_zebra_line_smoother_bit_exact(case, zsm):
+    """Zebra line Gauss-Seidel along y / along x: each colour pass solves every line of that colour with the
+    Thomas algorithm -- y-lines one thread per line with lanes along x, x-lines staged through LDS in 128-byte chunks so
+    that the march stays coalesced; same recurrences as the oracle => same bits."""
+    case = dict(case)
+    if zsm == capi.SMOOTH_ZEBRA_X:
+        case["aniso"] = (case["aniso"][1], case["aniso"][0], case["aniso"][2])   # the dominant coupling along the lines
+    kw = dict(levels=2, length=1.0, alpha=1.0, omega=1.0, smoother=zsm, **case)
     s, ops, do = pair(**kw)
     rng = np.random.default_rng(21)
     with s:
         shape = s.level_shape(0)
         u = rnd(rng, shape, s.np); b = rnd(rng, shape, s.np)
         s.set_array(capi.ARR_U, 0, u); s.set_array(capi.ARR_RHS, 0, b)
-        s.smooth(0, capi.SMOOTH_ZEBRA_Y, 1, capi.ARR_U, capi.ARR_RHS)
-        ref = ops.smooth(0, po.SMOOTH_ZEBRA_Y, 1, u, b)
+        s.smooth(0, zsm, 1, capi.ARR_U, capi.ARR_RHS)
+        ref = ops.smooth(0, zsm, 1, u, b)
         assert np.array_equal(s.get_array(capi.ARR_U, 0), ref)
-        s.smooth(0, capi.SMOOTH_ZEBRA_Y, 2, capi.ARR_U, capi.ARR_RHS)
-        assert np.array_equal(s.get_array(capi.ARR_U, 0), ops.smooth(0, po.SMOOTH_ZEBRA_Y, 2, ref, b))
+        s.smooth(0, zsm, 2, capi.ARR_U, capi.ARR_RHS)
+        assert np.array_equal(s.get_array(capi.ARR_U, 0), ops.smooth(0, zsm, 2, ref, b))
         # level 1 has its own factors
         sh1 = s.level_shape(1)
         u1 = rnd(rng, sh1, s.np); b1 = rnd(rng, sh1, s.np)
         s.set_array(capi.ARR_U, 1, u1); s.set_array(capi.ARR_RHS, 1, b1)
-        s.smooth(1, capi.SMOOTH_ZEBRA_Y, 1, capi.ARR_U, capi.ARR_RHS)
-        assert np.array_equal(s.get_array(capi.ARR_U, 1), ops.smooth(1, po.SMOOTH_ZEBRA_Y, 1, u1, b1))
+        s.smooth(1, zsm, 1, capi.ARR_U, capi.ARR_RHS)
+        assert np.array_equal(s.get_array(capi.ARR_U, 1), ops.smooth(1, zsm, 1, u1, b1))
 
 
 def test_zebra_smoother_needs_a_zebra_handle():
@@ -529,6 +549,7 @@ MANUFACTURED = [
     dict(id="semi-aniso-jacobi", smoother=capi.SMOOTH_JACOBI, omega=0.8, dtype=capi.MG_F64, aniso=(1.0, 1.0, 0.01), semi_xy=3, levels=5),
     dict(id="semi-aniso-rbgs", smoother=capi.SMOOTH_RBGS, omega=1.0, dtype=capi.MG_F64, aniso=(1.0, 1.0, 0.0625), semi_xy=2, levels=4),
     dict(id="zebra-y", smoother=capi.SMOOTH_ZEBRA_Y, omega=1.0, dtype=capi.MG_F64, aniso=(1.0, 100.0, 1.0)),
+    dict(id="zebra-x", smoother=capi.SMOOTH_ZEBRA_X, omega=1.0, dtype=capi.MG_F64, aniso=(100.0, 1.0, 1.0)),
     dict(id="inject-jacobi", smoother=capi.SMOOTH_JACOBI, omega=6 / 7, dtype=capi.MG_F64, restriction=capi.RESTRICT_INJECT),
 ]
 

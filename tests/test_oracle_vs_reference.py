@@ -153,8 +153,34 @@ def test_zebra_line_smoother_handles_a_dominant_y_coupling():
         h, _ = s.solve(1e-13, 6)
         facs[sm] = h[-1] / h[-2]
     assert facs[po.SMOOTH_RBGS] > 0.6 and facs[po.SMOOTH_ZEBRA_Y] < 0.05
+    # the same along x (lines on the fast axis) for a dominant x-coupling
+    kw.update(aniso=(100.0, 1.0, 1.0), smoother=po.SMOOTH_ZEBRA_X)
+    s = po.Solver(po.make_desc(**kw)); s.set_rhs(po.fill_rhs_3d(33, 1.0, 1.0, 1))
+    h, _ = s.solve(1e-13, 6)
+    assert h[-1] / h[-2] < 0.05
+    kw.update(smoother=po.SMOOTH_ZEBRA_Y)   # lines across the strong direction do not help
+    s = po.Solver(po.make_desc(**kw)); s.set_rhs(po.fill_rhs_3d(33, 1.0, 1.0, 1))
+    h, _ = s.solve(1e-13, 6)
+    assert h[-1] / h[-2] > 0.6
     # on the isotropic operator it is simply a stronger smoother than red-black
     kw.update(aniso=(1.0, 1.0, 1.0), smoother=po.SMOOTH_ZEBRA_Y)
     s = po.Solver(po.make_desc(**kw)); s.set_rhs(po.fill_rhs_3d(33, 1.0, 1.0, 1))
     h, _ = s.solve(1e-13, 6)
     assert h[-1] / h[-2] < 0.1
+
+
+def test_semi_coarsening_and_line_smoother_are_both_needed_for_config5_style_anisotropy():
+    """EXTENSION (BASELINE config 5: 'semi-coarsening + line smoother in the strong direction'; no reference
+    counterpart): -(dxx + 30 dyy + 0.05 dzz). Point smoothing with standard coarsening stalls, either ingredient
+    alone is not enough, both together restore multigrid convergence."""
+    fac = {}
+    for sm in (po.SMOOTH_RBGS, po.SMOOTH_ZEBRA_Y):
+        for semi in (0, 2):
+            kw = dict(dim=3, n=65, levels=4, dtype=po.MG_F64, length=1.0, alpha=1.0, cycle=po.CYCLE_V, nu_pre=2, nu_post=2,
+                      smoother=sm, omega=1.0, restriction=po.RESTRICT_FULLW, coarse_mode=po.COARSE_FIXED, coarse_maxit=30,
+                      outer_pre_gs=0, aniso=(1.0, 30.0, 0.05), semi_xy=semi)
+            s = po.Solver(po.make_desc(**kw)); s.set_rhs(po.fill_rhs_3d(65, 1.0, 1.0, 1))
+            h, _ = s.solve(1e-13, 6)
+            fac[(sm, semi)] = h[-1] / h[-2]
+    assert fac[(po.SMOOTH_RBGS, 0)] > 0.8 and fac[(po.SMOOTH_RBGS, 2)] > 0.6 and fac[(po.SMOOTH_ZEBRA_Y, 0)] > 0.4
+    assert fac[(po.SMOOTH_ZEBRA_Y, 2)] < 0.05
