@@ -1176,25 +1176,27 @@ __global__ __launch_bounds__(256) void k_zebra_y(Geom g, Coef<T> c, int colour, 
 // ---------------------------------------------------------------- zebra line Gauss-Seidel along x
 // One colour pass, lines along the FAST axis (EXTENSION), coloured by the parity of y (+ z). A thread
 // marching along its own line would use 8 bytes of every 128-byte line it touches, so a workgroup of ZXT threads takes
-// ZXT lines of the active colour and walks them in chunks of XC = 128 B / sizeof(T) columns:
-//   (A) all threads together evaluate R = b - S on the ZXT x XC tile -- 16 (32) consecutive lanes per line segment, so
-//       every access is a whole aligned 128-byte line -- into LDS;
+// ZXT lines of the active colour and walks them in chunks of XC = 256 B / sizeof(T) columns:
+//   (A) all threads together evaluate R = b - S on the ZXT x XC tile -- 32 (64) consecutive lanes per line segment, so
+//       every access is two whole aligned 128-byte lines -- into LDS;
 //   (B) thread t runs the elimination recurrence of line t over the chunk's columns out of LDS (rows padded to an odd
 //       stride: conflict-free), carrying dp(x-1) in a register from chunk to chunk;
 //   (C) the tile goes to the dp scratch array, coalesced again.
 // The back substitution walks the chunks in reverse the same way. Per line the operations and their order are those of
 // the CPU restatement's sequential Thomas solve => same bits; lines never cross a z-slab.
-constexpr int ZXT = 256;
+constexpr int ZXT = 128;
 
 template <typename T, int DIM>
 __global__ __launch_bounds__(ZXT) void k_zebra_x(Geom g, Coef<T> c, int colour, T *__restrict__ u, const T *__restrict__ rhs,
                                                  T *__restrict__ dp, const T *__restrict__ cp, const T *__restrict__ den,
                                                  int lpp, int nlines)
 {
-    constexpr int XC = 128 / (int)sizeof(T), LP = XC + 1;
+    constexpr int XC = 256 / (int)sizeof(T), LP = XC + 1;  // two 128-byte lines per line and chunk
+    constexpr int UB = 8;                                   // tile points per thread whose loads are issued together
     __shared__ T tile[ZXT][LP];
     __shared__ long long lbase[ZXT];
     __shared__ int lflag[ZXT];  // 0: no such line, 1: interior line, 2: line inside the boundary (identity rows)
+    __shared__ T sfac[XC];      // den(x) / cp(x) of the chunk: read inside the recurrence, so they must not come from global memory there
     const int t = threadIdx.x;
     {
         const int L = blockIdx.x * ZXT + t;  // line slot: z = L / lpp, y = 2 (L % lpp) + parity
@@ -1209,70 +1211,91 @@ __global__ __launch_bounds__(ZXT) void k_zebra_x(Geom g, Coef<T> c, int colour, 
     __syncthreads();
     const int nx = g.nx, nch = (nx + XC - 1) / XC;
     const int myflag = lflag[t];
+    // tile point q of this thread: q-th group of ZXT consecutive points, XC consecutive points per line
+    auto line_of = [&](int q) { return (q * ZXT + t) / XC; };
+    auto col_of = [&](int q) { return (q * ZXT + t) % XC; };
     T carry = 0;  // dp(x-1) of the thread's own line
     for (int ch = 0; ch < nch; ch++) {
-        const int x0 = ch * XC;
-        for (int p = t; p < ZXT * XC; p += ZXT) {  // (A)
-            const int ll = p / XC, col = p % XC, x = x0 + col;
-            const int fl = lflag[ll];
-            T R = 0;
-            if (fl && x < nx) {
-                const long long idx = lbase[ll] + x;
-                R = rhs[idx];
-                if (fl == 1 && x > 0 && x < nx - 1) {
+        const int x0 = ch * XC, ncol = min(XC, nx - x0);
+        if (t < XC) sfac[t] = den[min(x0 + t, nx - 1)];
+        for (int q0 = 0; q0 < XC; q0 += UB) {  // (A): UB points at a time, every load of the batch before its arithmetic
+            T b[UB], um[UB], up[UB], zm[UB], zp[UB];
+            int fl[UB];
+#pragma unroll
+            for (int k = 0; k < UB; k++) {
+                const int ll = line_of(q0 + k), x = x0 + col_of(q0 + k);
+                fl[k] = (x < nx) ? lflag[ll] : 0;
+                const long long idx = lbase[ll] + min(x, nx - 1);
+                const bool inner = fl[k] == 1 && x > 0 && x < nx - 1;
+                b[k] = fl[k] ? rhs[idx] : (T)0;
+                um[k] = inner ? u[idx - g.pitch] : (T)0;
+                up[k] = inner ? u[idx + g.pitch] : (T)0;
+                zm[k] = (DIM == 3 && inner) ? u[idx - g.plane] : (T)0;
+                zp[k] = (DIM == 3 && inner) ? u[idx + g.plane] : (T)0;
+                if (!inner) fl[k] = fl[k] ? 2 : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < UB; k++) {
+                T R = b[k];
+                if (fl[k] == 1) {
                     T S = 0;
-                    if (DIM == 3) S += c.cz * u[idx - g.plane];
-                    S += c.cy * u[idx - g.pitch];
-                    S += c.cy * u[idx + g.pitch];
-                    if (DIM == 3) S += c.cz * u[idx + g.plane];
+                    if (DIM == 3) S += c.cz * zm[k];
+                    S += c.cy * um[k];
+                    S += c.cy * up[k];
+                    if (DIM == 3) S += c.cz * zp[k];
                     R = R - S;
                 }
+                tile[line_of(q0 + k)][col_of(q0 + k)] = R;
             }
-            tile[ll][col] = R;
         }
         __syncthreads();
         if (myflag == 1) {  // (B) dp(0) = b(0); dp(x) = (R(x) - cx dp(x-1)) / den(x); the last column keeps b(nx-1)
-#pragma unroll 4
+#pragma unroll 8
             for (int col = 0; col < XC; col++) {
                 const int x = x0 + col;
-                if (x >= nx) break;
                 const T r = tile[t][col];
-                if (x == 0 || x == nx - 1) carry = r;
-                else carry = (r - c.cx * carry) / den[x];
-                tile[t][col] = carry;
+                T nc = (r - c.cx * carry) / sfac[col];
+                if (x == 0 || x == nx - 1) nc = r;
+                if (col < ncol) { carry = nc; tile[t][col] = nc; }
             }
         }
         __syncthreads();
-        for (int p = t; p < ZXT * XC; p += ZXT) {  // (C)
-            const int ll = p / XC, col = p % XC, x = x0 + col;
+#pragma unroll 4
+        for (int q = 0; q < XC; q++) {  // (C)
+            const int ll = line_of(q), col = col_of(q), x = x0 + col;
             if (lflag[ll] && x < nx) dp[lbase[ll] + x] = tile[ll][col];
         }
         __syncthreads();
     }
     // back substitution: u(nx-1) = b(nx-1); u(x) = dp(x) - cp(x) u(x+1); u(0) = dp(0)
     for (int ch = nch - 1; ch >= 0; ch--) {
-        const int x0 = ch * XC;
-        for (int p = t; p < ZXT * XC; p += ZXT) {
-            const int ll = p / XC, col = p % XC, x = x0 + col;
-            T v = 0;
-            if (lflag[ll] && x < nx) v = dp[lbase[ll] + x];
-            tile[ll][col] = v;
+        const int x0 = ch * XC, ncol = min(XC, nx - x0);
+        if (t < XC) sfac[t] = cp[min(x0 + t, nx - 1)];
+        for (int q0 = 0; q0 < XC; q0 += UB) {
+            T v[UB];
+#pragma unroll
+            for (int k = 0; k < UB; k++) {
+                const int ll = line_of(q0 + k), x = x0 + col_of(q0 + k);
+                v[k] = (lflag[ll] && x < nx) ? dp[lbase[ll] + x] : (T)0;
+            }
+#pragma unroll
+            for (int k = 0; k < UB; k++) tile[line_of(q0 + k)][col_of(q0 + k)] = v[k];
         }
         __syncthreads();
         if (myflag == 1) {
-#pragma unroll 4
+#pragma unroll 8
             for (int col = XC - 1; col >= 0; col--) {
                 const int x = x0 + col;
-                if (x >= nx) continue;
                 const T d = tile[t][col];
-                if (x == 0 || x == nx - 1) carry = d;
-                else carry = d - cp[x] * carry;
-                tile[t][col] = carry;
+                T nc = d - sfac[col] * carry;
+                if (x == 0 || x == nx - 1) nc = d;
+                if (col < ncol) { carry = nc; tile[t][col] = nc; }
             }
         }
         __syncthreads();
-        for (int p = t; p < ZXT * XC; p += ZXT) {
-            const int ll = p / XC, col = p % XC, x = x0 + col;
+#pragma unroll 4
+        for (int q = 0; q < XC; q++) {
+            const int ll = line_of(q), col = col_of(q), x = x0 + col;
             if (lflag[ll] && x < nx) u[lbase[ll] + x] = tile[ll][col];
         }
         __syncthreads();
