@@ -22,6 +22,7 @@
 // MFMA is not used: there is no contraction here, the kernel is HBM-bound (24 B/point).
 #include "mg_kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace mg {
@@ -63,7 +64,7 @@ __device__ __forceinline__ double wave_sum64(double v)
 
 enum { OP_JACOBI = 0, OP_RESIDUAL = 1, OP_RB = 2 };
 
-constexpr int RY = 2, BW = 4, ZC = 3;
+constexpr int RY = 2, BW = 4, ZC = 3;  // ZC: planes marched per workgroup on a level big enough to fill the chip
 
 // OP_JACOBI : out = Jacobi update (DAMPED selects omega != 1)
 // OP_RESIDUAL: out = rhs - A u (stored if SAVE), sum r^2 -> partials[block] if NORM
@@ -95,8 +96,9 @@ __global__ __launch_bounds__(64 * BW) void k_sweep3d(Geom g, Coef<T> c, T omega,
         const bool xin = x0 < V * nvec;
         const int x0c = min(x0, g.pitch - V);  // clamped for loads: every lane stays active
         const int yb = (by * BW + wv) * RY;
-        const int z0 = bz * ZC;
-        const int zend = min(z0 + ZC, g.nz);
+        const int zc = (g.nz + nbz - 1) / nbz;   // planes marched per workgroup (the launcher picks nbz)
+        const int z0 = bz * zc;
+        const int zend = min(z0 + zc, g.nz);
         // does this wave hold the last full vector of the row? then it also writes column nx-1
         const bool tailwave = (g.nx % V == 1) && (bx * 64 * V <= g.nx - 1 - V) && (g.nx - 1 - V < (bx + 1) * 64 * V);
 
@@ -613,6 +615,9 @@ FastGrid fast_grid(const Geom &g)
     f.nbx = (g.nx / V + 63) / 64;
     f.nby = (g.ny + RY * BW - 1) / (RY * BW);
     f.nbz = (g.nz + ZC - 1) / ZC;
+    // small levels (<= 65^3 in fp64) are latency-bound: every marched plane is one more dependent memory round trip
+    // and the grid does not fill the chip anyway -- one plane per workgroup there (7.8 -> ~5 us per sweep at 65^3)
+    if (f.nbx * f.nby * f.nbz < 1024) f.nbz = g.nz;
     int nblocks = f.nbx * f.nby * f.nbz;
     f.grid = ((nblocks + 7) / 8) * 8;
     return f;
@@ -631,7 +636,9 @@ bool fast_path_ok(const Geom &g)
 template <typename T>
 int fast_partials_capacity(const Geom &g)
 {
-    return fast_path_ok<T>(g) ? fast_grid<T>(g).grid : 0;
+    if (!fast_path_ok<T>(g)) return 0;
+    const FastGrid f = fast_grid<T>(g);   // upper bound over both march lengths (sub-slabs of a level may pick the other one)
+    return std::max(f.grid, ((f.nbx * f.nby * g.nz + 7) / 8) * 8);
 }
 
 // arrays larger than this stream through the caches: use non-temporal rhs loads

@@ -413,7 +413,10 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
     const int nw = (ncol + 64 * CV - 1) / (64 * CV);          // waves side by side in x (<= 8)
     const int nby = (gc.ny + CR - 1) / CR;
     static const int zcc_env = [] { const char *e = getenv("MG_RR_ZCC"); return e ? atoi(e) : 0; }();
-    const int zcc = zcc_env > 0 ? zcc_env : 4;               // coarse planes marched per workgroup
+    int zcc = zcc_env > 0 ? zcc_env : 4;                     // coarse planes marched per workgroup
+    // small levels are latency-bound (one dependent memory round trip per marched plane) and their grids do not fill
+    // the chip: one coarse plane per workgroup there
+    if (zcc_env <= 0 && nby * ((gc.nz + zcc - 1) / zcc) < 1024) zcc = 1;
     const int nbz = (gc.nz + zcc - 1) / zcc;
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool nt = (size_t)gf.nz * gf.plane * sizeof(T) >= ((size_t)64 << 20);
