@@ -270,10 +270,12 @@ def main():
     barrier()
     # timed region: exactly K cycles, finest-level launches bracketed by HIP events
     s.profile_begin()
+    groups0, sent0 = s.comm_stats()
     t0 = time.perf_counter()
     s.cycle_async(a.steps)
     barrier()
     t1 = time.perf_counter()
+    groups1, sent1 = s.comm_stats()
     _, sm_sweeps = s.profile_end()
     prof = {k: s.profile_get(getattr(capi, "PROF_" + k)) for k in ("SMOOTH", "SMOOTH_PROLONG", "RESID_RESTRICT", "PROLONG")}
     elapsed = t1 - t0
@@ -363,6 +365,9 @@ def main():
                    "first_gathered_level": first_gathered},
         "transport": transport_name, "rccl_ranks": transport_ranks if transport_name == "rccl" else None,
         "ms_per_step_ranks": per_rank_ms,
+        # what rank 0 posts per cycle: message groups (halo exchanges, gather, scatter: one ncclGroup each) and bytes sent
+        "comm_per_cycle": ({"message_groups": (groups1 - groups0) / a.steps, "bytes_sent": (sent1 - sent0) / a.steps}
+                           if world > 1 else None),
         "ms_per_step_with_residual_norm": solve_ms_per_cycle,
         "roofline": {"bound": "hbm",
                      "kernel": (f"finest-grid fused double Jacobi sweep k_jacobi2 ({a.n}^3, two sweeps in one pass over HBM)" if fused_pair

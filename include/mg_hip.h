@@ -173,6 +173,9 @@ int mg_comm_selftest(size_t bytes);
 /* rank / size of the handle's decomposition and what the transport itself reports (RCCL: ncclCommCount;
  * 1 for a single-GPU handle); transport = "none" | "rccl" | "host-callbacks" (static string) */
 int mg_comm_info(mg_handle h, int *rank, int *nranks, int *transport_ranks, const char **transport);
+/* cumulative communication of this rank since creation: message groups posted (halo exchanges, gathers, scatters,
+ * all-reduces: one ncclGroup / one host batch each) and bytes sent in them */
+int mg_comm_stats(mg_handle h, long long *groups, long long *bytes_sent);
 /* like mg_create, for rank `rank` of `nranks` (one process per GPU) */
 int mg_create_distributed(const mg_desc *desc, int device, int rank, int nranks,
                           const void *id128, mg_handle *out);

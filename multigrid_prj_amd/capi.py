@@ -88,7 +88,7 @@ EXPORTS = [
     "mg_level_coefficients", "mg_set_rhs", "mg_set_solution", "mg_get_solution", "mg_set_array",
     "mg_get_array", "mg_zero_array", "mg_smooth", "mg_residual", "mg_sumsq", "mg_restrict",
     "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_coarse_solve_ex", "mg_cycle", "mg_cycle_async", "mg_solve", "mg_solve_lockstep",
-    "mg_set_stage_callback", "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_profile_fused", "mg_profile_get", "mg_comm_info", "mg_device_bytes", "mg_comm_unique_id", "mg_comm_selftest",
+    "mg_set_stage_callback", "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_profile_fused", "mg_profile_get", "mg_comm_info", "mg_comm_stats", "mg_device_bytes", "mg_comm_unique_id", "mg_comm_selftest",
     "mg_create_distributed", "mg_create_distributed_hostcomm", "mg_plan_slab",
 ]
 
@@ -141,6 +141,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.mg_profile_fused.argtypes = [vp, dp, C.POINTER(i)]
     L.mg_profile_get.argtypes = [vp, i, dp, C.POINTER(i)]
     L.mg_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(C.c_char_p)]
+    L.mg_comm_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.mg_device_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.mg_comm_unique_id.argtypes = [vp]
     L.mg_comm_selftest.argtypes = [C.c_size_t]
@@ -340,6 +341,11 @@ class Solver:
         r, n, t = C.c_int(0), C.c_int(0), C.c_int(0); name = C.c_char_p()
         _check(self.lib.mg_comm_info(self.h, C.byref(r), C.byref(n), C.byref(t), C.byref(name)))
         return r.value, n.value, t.value, name.value.decode()
+
+    def comm_stats(self):
+        """-> (message groups posted, bytes sent) by this rank since creation"""
+        g, b = C.c_longlong(0), C.c_longlong(0)
+        _check(self.lib.mg_comm_stats(self.h, C.byref(g), C.byref(b))); return g.value, b.value
 
     def device_bytes(self) -> int:
         b = C.c_size_t(0); _check(self.lib.mg_device_bytes(self.h, C.byref(b))); return b.value

@@ -186,6 +186,13 @@ int mg_comm_info(mg_handle h, int *rank, int *nranks, int *transport_ranks, cons
     MG_H(h);
     return guarded([&] { return h->impl->comm_info(rank, nranks, transport_ranks, transport); });
 }
+int mg_comm_stats(mg_handle h, long long *groups, long long *bytes_sent)
+{
+    MG_H(h);
+    if (groups) *groups = h->impl->comm_groups();
+    if (bytes_sent) *bytes_sent = h->impl->comm_bytes_sent();
+    return MG_OK;
+}
 int mg_device_bytes(mg_handle h, size_t *bytes)
 {
     MG_H(h);

@@ -65,6 +65,8 @@ void launch_prolong_fast(hipStream_t s, const Geom &gc, const Geom &gf, const T 
 
 // fused residual + full-weighting restriction (non-distributed 3-D levels): coarse = R (rhs - A u)
 template <typename T> bool resid_restrict_fast_ok(const Geom &gf, const Geom &gc);
+// the same launcher on a z-slab (two ghost planes of u and one of rhs below the slab must be valid)
+template <typename T> bool resid_restrict_slab_ok(const Geom &gf, const Geom &gc);
 template <typename T>
 void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, const Coef<T> &c, const T *u,
                               const T *rhs, T *coarse);

@@ -260,7 +260,8 @@ int Solver::init()
                 bytes_ += nbytes;
             }
         }
-        L.alloc_elems = (size_t)(L.g.nz + 2) * (size_t)L.g.plane;
+        L.gh = L.dist ? 2 : 1;
+        L.alloc_elems = (size_t)(L.g.nz + 2 * L.gh) * (size_t)L.g.plane;
         if (!L.present) continue;
         for (int a = 0; a < NUM_ARR; a++) {
             if (a == MG_ARR_RES && l > 0) continue;
@@ -315,7 +316,7 @@ template <typename T>
 T *Solver::ptr(int which, int level) const
 {
     const Level &L = lv_[level];
-    return reinterpret_cast<T *>(L.base[which]) + L.g.plane;  // skip the lower ghost plane
+    return reinterpret_cast<T *>(L.base[which]) + L.gh * L.g.plane;  // skip the lower ghost plane(s)
 }
 
 // Host <-> device copies of a level's array (dense rows on the host, 128-byte-pitched rows on the device)
@@ -338,7 +339,8 @@ int Solver::stage_rows(int which, int level, void *host, bool to_device)
         MG_HIP(hipHostMalloc(&h_stage_, h_stage_bytes_));
     }
     const int per = (int)std::max<size_t>(1, h_stage_bytes_ / pbytes);  // planes per chunk
-    char *dev = reinterpret_cast<char *>(L.base[which]) + pbytes;      // local plane 0
+    char *dev = reinterpret_cast<char *>(L.base[which]) + (size_t)L.gh * pbytes;      // local plane 0
+    if (to_device && which == MG_ARR_RHS) lv_[level].rhs_halo_ok = false;
     char *st = reinterpret_cast<char *>(h_stage_);
     char *hp = reinterpret_cast<char *>(host);
     for (int z0 = 0; z0 < L.g.nz; z0 += per) {
@@ -379,51 +381,61 @@ int Solver::get_array(int which, int level, void *host)
 int Solver::zero_array(int which, int level)
 {
     if (!check_arr(which, level, "mg_zero_array")) return MG_ERR_BAD_ARG;
+    if (which == MG_ARR_RHS) lv_[level].rhs_halo_ok = false;
     MG_HIP(hipMemsetAsync(lv_[level].base[which], 0, lv_[level].alloc_elems * esize(), stream_));
     return MG_OK;
 }
 
 #define MG_TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
-int Solver::exchange(int which, int level)
+int Solver::post(const P2POp *ops, int n, hipStream_t s)
+{
+    if (n > 0) comm_groups_++;
+    for (int i = 0; i < n; i++) if (ops[i].send) comm_bytes_ += (long long)ops[i].bytes;
+    return comm_->batch(ops, n, s);
+}
+
+// The halo operations of `depth` planes with the z-neighbours: my first / last `depth` owned planes go to their upper / lower
+// ghost planes, theirs come into mine. Owned and ghost planes are contiguous, so each is one message. Returns the op count.
+int Solver::halo_ops(int which, int level, int depth, P2POp *ops)
+{
+    Level &L = lv_[level];
+    const size_t pb = (size_t)L.g.plane * esize();
+    char *b = reinterpret_cast<char *>(L.base[which]);
+    const size_t own0 = (size_t)L.gh * pb, nzb = (size_t)L.g.nz * pb, db = (size_t)depth * pb;
+    int n = 0;
+    if (rank_ > 0) {
+        ops[n++] = P2POp{rank_ - 1, true, b + own0, db};                   // my first planes -> their upper ghosts
+        ops[n++] = P2POp{rank_ - 1, false, b + own0 - db, db};             // their last planes -> my lower ghosts
+    }
+    if (rank_ < nranks_ - 1) {
+        ops[n++] = P2POp{rank_ + 1, true, b + own0 + nzb - db, db};        // my last planes -> their lower ghosts
+        ops[n++] = P2POp{rank_ + 1, false, b + own0 + nzb, db};
+    }
+    return n;
+}
+
+int Solver::exchange(int which, int level, int depth)
 {
     Level &L = lv_[level];
     if (!L.dist) return MG_OK;
-    const size_t pb = (size_t)L.g.plane * esize();
-    char *b = reinterpret_cast<char *>(L.base[which]);
+    if (depth > L.gh || depth > L.g.nz) { set_last_error("halo exchange deeper than the ghost planes / the slab"); return MG_ERR_BAD_ARG; }
     P2POp ops[4];
-    int n = 0;
-    if (rank_ > 0) {
-        ops[n++] = P2POp{rank_ - 1, true, b + pb, pb};                       // my first plane -> their upper ghost
-        ops[n++] = P2POp{rank_ - 1, false, b, pb};                           // their last plane -> my lower ghost
-    }
-    if (rank_ < nranks_ - 1) {
-        ops[n++] = P2POp{rank_ + 1, true, b + (size_t)L.g.nz * pb, pb};      // my last plane -> their lower ghost
-        ops[n++] = P2POp{rank_ + 1, false, b + (size_t)(L.g.nz + 1) * pb, pb};
-    }
-    int rc = comm_->batch(ops, n, stream_);
+    const int n = halo_ops(which, level, depth, ops);
+    int rc = post(ops, n, stream_);
     if (rc) set_last_error("halo exchange failed");
     return rc;
 }
 
-int Solver::exchange_begin(int which, int level)
+int Solver::exchange_begin(int which, int level, int depth)
 {
     Level &L = lv_[level];
-    const size_t pb = (size_t)L.g.plane * esize();
-    char *b = reinterpret_cast<char *>(L.base[which]);
+    if (depth > L.gh || depth > L.g.nz) { set_last_error("halo exchange deeper than the ghost planes / the slab"); return MG_ERR_BAD_ARG; }
     P2POp ops[4];
-    int n = 0;
-    if (rank_ > 0) {
-        ops[n++] = P2POp{rank_ - 1, true, b + pb, pb};
-        ops[n++] = P2POp{rank_ - 1, false, b, pb};
-    }
-    if (rank_ < nranks_ - 1) {
-        ops[n++] = P2POp{rank_ + 1, true, b + (size_t)L.g.nz * pb, pb};
-        ops[n++] = P2POp{rank_ + 1, false, b + (size_t)(L.g.nz + 1) * pb, pb};
-    }
+    const int n = halo_ops(which, level, depth, ops);
     MG_HIP(hipEventRecord(ev_ready_, stream_));
     MG_HIP(hipStreamWaitEvent(comm_stream_, ev_ready_, 0));
-    int rc = comm_->batch(ops, n, comm_stream_);
+    int rc = post(ops, n, comm_stream_);
     if (rc) { set_last_error("halo exchange failed"); return rc; }
     MG_HIP(hipEventRecord(ev_halo_, comm_stream_));
     return MG_OK;
@@ -469,10 +481,10 @@ int Solver::gather_S(int arr)
         std::vector<P2POp> ops;
         for (int r = 1; r < nranks_; r++)
             ops.push_back(P2POp{r, false, f + (size_t)(1 + planS_[r].z0) * pb, (size_t)planS_[r].nz * pb});
-        rc = comm_->batch(ops.data(), (int)ops.size(), stream_);
+        rc = post(ops.data(), (int)ops.size(), stream_);
     } else {
         P2POp op{0, true, sb + pb, (size_t)stage_g_.nz * pb};
-        rc = comm_->batch(&op, 1, stream_);
+        rc = post(&op, 1, stream_);
     }
     if (rc) set_last_error("gather to rank 0 failed");
     return rc;
@@ -492,10 +504,10 @@ int Solver::scatter_S(int arr)
         std::vector<P2POp> ops;
         for (int r = 1; r < nranks_; r++)
             ops.push_back(P2POp{r, true, f + (size_t)(1 + planS_[r].z0) * pb, planes(r) * pb});
-        rc = comm_->batch(ops.data(), (int)ops.size(), stream_);
+        rc = post(ops.data(), (int)ops.size(), stream_);
     } else {
         P2POp op{0, false, sb + pb, planes(rank_) * pb};
-        rc = comm_->batch(&op, 1, stream_);
+        rc = post(&op, 1, stream_);
     }
     if (rc) set_last_error("scatter from rank 0 failed");
     return rc;
@@ -509,14 +521,14 @@ int Solver::gather_T(int which, int fullk)
     int rc;
     if (rank_ == 0) {
         char *f = reinterpret_cast<char *>(full_[fullk]);
-        MG_HIP(hipMemcpyAsync(f + pb, b + pb, (size_t)L.g.nz * pb, hipMemcpyDeviceToDevice, stream_));
+        MG_HIP(hipMemcpyAsync(f + pb, b + (size_t)L.gh * pb, (size_t)L.g.nz * pb, hipMemcpyDeviceToDevice, stream_));
         std::vector<P2POp> ops;
         for (int r = 1; r < nranks_; r++)
             ops.push_back(P2POp{r, false, f + (size_t)(1 + planT_[r].z0) * pb, (size_t)planT_[r].nz * pb});
-        rc = comm_->batch(ops.data(), (int)ops.size(), stream_);
+        rc = post(ops.data(), (int)ops.size(), stream_);
     } else {
-        P2POp op{0, true, b + pb, (size_t)L.g.nz * pb};
-        rc = comm_->batch(&op, 1, stream_);
+        P2POp op{0, true, b + (size_t)L.gh * pb, (size_t)L.g.nz * pb};
+        rc = post(&op, 1, stream_);
     }
     if (rc) set_last_error("gather to rank 0 failed");
     return rc;
@@ -530,14 +542,14 @@ int Solver::scatter_T(int fullk, int which)
     int rc;
     if (rank_ == 0) {
         char *f = reinterpret_cast<char *>(full_[fullk]);
-        MG_HIP(hipMemcpyAsync(b + pb, f + pb, (size_t)L.g.nz * pb, hipMemcpyDeviceToDevice, stream_));
+        MG_HIP(hipMemcpyAsync(b + (size_t)L.gh * pb, f + pb, (size_t)L.g.nz * pb, hipMemcpyDeviceToDevice, stream_));
         std::vector<P2POp> ops;
         for (int r = 1; r < nranks_; r++)
             ops.push_back(P2POp{r, true, f + (size_t)(1 + planT_[r].z0) * pb, (size_t)planT_[r].nz * pb});
-        rc = comm_->batch(ops.data(), (int)ops.size(), stream_);
+        rc = post(ops.data(), (int)ops.size(), stream_);
     } else {
-        P2POp op{0, false, b + pb, (size_t)L.g.nz * pb};
-        rc = comm_->batch(&op, 1, stream_);
+        P2POp op{0, false, b + (size_t)L.gh * pb, (size_t)L.g.nz * pb};
+        rc = post(&op, 1, stream_);
     }
     if (rc) set_last_error("scatter from rank 0 failed");
     return rc;
@@ -546,6 +558,7 @@ int Solver::scatter_T(int fullk, int which)
 int Solver::allreduce(double *dptr, int n)
 {
     if (nranks_ == 1) return MG_OK;
+    comm_groups_++; comm_bytes_ += 8LL * n;
     int rc = comm_->allreduce_sum(dptr, n, stream_);
     if (rc) set_last_error("allreduce failed");
     return rc;
@@ -631,6 +644,93 @@ int Solver::pair_on_slab_t(int level, bool rb)
     return MG_OK;
 }
 
+static bool depth2_enabled()
+{
+    static const bool e = [] { const char *v = getenv("MG_DEPTH2"); return !(v && v[0] == '0'); }();
+    return e;
+}
+
+int Solver::refresh_rhs_halo(int level)
+{
+    Level &L = lv_[level];
+    if (!L.dist || L.rhs_halo_ok) return MG_OK;
+    MG_TRY(exchange(MG_ARR_RHS, level, 1));
+    L.rhs_halo_ok = true;
+    return MG_OK;
+}
+
+// The same pair (or red-black sweep) with TWO ghost planes: one exchange of two planes of u, then the fused kernel on the
+// whole slab -- its first sweep is evaluated on the ghost planes -1 and nz as well (redundantly with the neighbour, from
+// u on planes -2 .. nz+1 and the neighbour's rhs plane, which is exchanged once per right-hand side). One message pair
+// per neighbour and pair instead of two, three launches instead of five; the interior output planes 2 .. nz-3 need no
+// ghost plane at all and run while the halo moves. Same arithmetic per point => same bits as one GPU.
+template <typename T>
+int Solver::pair_on_slab2_t(int level, bool rb)
+{
+    Level &L = lv_[level];
+    const Geom &g = L.g;
+    Coef<T> c = coef_of<T>(L);
+    const T om = (T)d_.omega;
+    T *px = ptr<T>(MG_ARR_U, level), *pr = ptr<T>(MG_ARR_RHS, level), *pt = ptr<T>(MG_ARR_TMP, level);
+    const long long pl = g.plane;
+    auto fused = [&](const Geom &gs, long long off) {
+        if (rb) launch_rb_fused<T>(stream_, gs, c, px + off, pr + off, pt + off, (const T *)nullptr, gs);
+        else launch_jacobi2<T>(stream_, gs, c, om, px + off, pr + off, pt + off, false);
+    };
+    MG_TRY(refresh_rhs_halo(level));
+    if (!overlap_ || g.nz < 8) {
+        MG_TRY(exchange(MG_ARR_U, level, 2));
+        fused(g, 0);
+    } else {
+        MG_TRY(exchange_begin(MG_ARR_U, level, 2));
+        Geom gi = g; gi.nz = g.nz - 4; gi.gz0 = g.gz0 + 2;     // reads u on planes 0 .. nz-1 only
+        fused(gi, 2 * pl);
+        MG_TRY(exchange_end());
+        Geom glo = g; glo.nz = 2;
+        fused(glo, 0);
+        Geom ghi = g; ghi.nz = 2; ghi.gz0 = g.gz0 + g.nz - 2;
+        fused(ghi, (long long)(g.nz - 2) * pl);
+    }
+    MG_HIP(hipGetLastError());
+    std::swap(L.base[MG_ARR_U], L.base[MG_ARR_TMP]);
+    return MG_OK;
+}
+
+// Residual + full weighting of a distributed level in one kernel: coarse = R (rhs - A u) for the coarse planes that coincide
+// with this rank's fine planes. The lowest of them needs the residual on the ghost plane -1, i.e. u on planes -2 .. 0 and
+// the neighbour's rhs plane: one exchange of two planes of u (none of the residual, which is never stored).
+template <typename T>
+int Solver::resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs)
+{
+    Level &L = lv_[level];
+    const Geom &gf = L.g;
+    const Coef<T> c = coef_of<T>(L);
+    T *pu = ptr<T>(MG_ARR_U, level), *pr = ptr<T>(MG_ARR_RHS, level);
+    MG_TRY(refresh_rhs_halo(level));
+    const bool semi = gf.gnz == gc.gnz;          // planes map one to one
+    if (!overlap_ || gc.nz < 4 || semi) {
+        MG_TRY(exchange(MG_ARR_U, level, 2));
+        launch_resid_restrict_fw<T>(stream_, gf, gc, c, pu, pr, coarse_rhs);
+    } else {
+        // coarse planes 1 .. nzc-2 read u on owned planes only: they run while the halo moves
+        MG_TRY(exchange_begin(MG_ARR_U, level, 2));
+        Geom gci = gc; gci.nz = gc.nz - 2; gci.gz0 = gc.gz0 + 1;
+        Geom gfi = gf; gfi.nz = 2 * gci.nz; gfi.gz0 = gf.gz0 + 2;
+        launch_resid_restrict_fw<T>(stream_, gfi, gci, c, pu + 2 * gf.plane, pr + 2 * gf.plane, coarse_rhs + gc.plane);
+        MG_TRY(exchange_end());
+        Geom gc0 = gc; gc0.nz = 1;
+        Geom gf0 = gf; gf0.nz = 2;
+        launch_resid_restrict_fw<T>(stream_, gf0, gc0, c, pu, pr, coarse_rhs);
+        const int kl = gc.nz - 1;                 // last coarse plane: fine planes 2 kl (and 2 kl + 1 unless it is the grid's top plane)
+        Geom gc1 = gc; gc1.nz = 1; gc1.gz0 = gc.gz0 + kl;
+        Geom gf1 = gf; gf1.nz = gf.nz - 2 * kl; gf1.gz0 = gf.gz0 + 2 * kl;
+        launch_resid_restrict_fw<T>(stream_, gf1, gc1, c, pu + (long long)2 * kl * gf.plane, pr + (long long)2 * kl * gf.plane,
+                                    coarse_rhs + (long long)kl * gc.plane);
+    }
+    MG_HIP(hipGetLastError());
+    return MG_OK;
+}
+
 // corr_level >= 0: x is still missing the coarse-grid correction P u_{corr_level}; the first fused
 // pair applies it on the fly (caller checked can_fold_prolong)
 // e_scratch: the level's E array may be used as scratch (true only inside the V-cycle, where E is idle): the
@@ -647,6 +747,17 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
     switch (smoother) {
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
+            if (L.dist && depth2_enabled() && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps && jacobi2_slab_ok<T>(L.g)) {
+                if (x_zero && s == 0) {  // zero guess on every rank: no halo of u to fetch at all, only the neighbours' rhs planes
+                    MG_TRY(refresh_rhs_halo(level));
+                    launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level), true);
+                    std::swap(L.base[ax], L.base[MG_ARR_TMP]);
+                } else {
+                    MG_TRY(pair_on_slab2_t<T>(level, false));
+                }
+                s++; launches += 3;
+                continue;
+            }
             if (L.dist && overlap_ && e_scratch && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps &&
                 !(x_zero && s == 0) && jacobi2_slab_ok<T>(L.g)) {  // E is free in a V-cycle: scratch for the boundary planes' first sweep
                 MG_TRY(pair_on_slab_t<T>(level, false));
@@ -681,6 +792,11 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
         break;
     case MG_SMOOTH_RBGS:
         for (int s = 0; s < sweeps; s++) {
+            if (L.dist && depth2_enabled() && ax == MG_ARR_U && ar == MG_ARR_RHS && jacobi2_slab_ok<T>(L.g) && rb_slab_enabled()) {
+                MG_TRY(pair_on_slab2_t<T>(level, true));   // one-pass red-black sweep on the whole slab, two ghost planes
+                launches += 3;
+                continue;
+            }
             if (L.dist && overlap_ && e_scratch && ax == MG_ARR_U && ar == MG_ARR_RHS &&
                 jacobi2_slab_ok<T>(L.g) && rb_slab_enabled()) {  // one-pass red-black sweep on the slab's inner planes
                 MG_TRY(pair_on_slab_t<T>(level, true));
@@ -752,6 +868,7 @@ int Solver::smooth(int level, int smoother, int sweeps, int arr_x, int arr_rhs)
         return MG_ERR_BAD_ARG;
     }
     MG_HIP(hipSetDevice(device_));
+    if (arr_x == MG_ARR_RHS) lv_[level].rhs_halo_ok = false;
     return d_.dtype == MG_F64 ? smooth_t<double>(level, smoother, sweeps, arr_x, arr_rhs)
                               : smooth_t<float>(level, smoother, sweeps, arr_x, arr_rhs);
 }
@@ -786,6 +903,7 @@ int Solver::residual(int level, int arr_x, int arr_rhs, int arr_r, double *sumsq
         return MG_ERR_BAD_ARG;
     }
     MG_HIP(hipSetDevice(device_));
+    if (arr_r == MG_ARR_RHS) lv_[level].rhs_halo_ok = false;
     int rc = d_.dtype == MG_F64 ? residual_t<double>(level, arr_x, arr_rhs, arr_r, true)
                                 : residual_t<float>(level, arr_x, arr_rhs, arr_r, true);
     if (rc) return rc;
@@ -825,6 +943,7 @@ int Solver::restrict_t(int fl, int kind, int as, int ad)
         set_last_error("transfer across the gather level is only available inside mg_cycle");
         return MG_ERR_BAD_ARG;
     }
+    if (ad == MG_ARR_RHS) lv_[fl + 1].rhs_halo_ok = false;
     if (kind == MG_RESTRICT_FULLW) MG_TRY(exchange(as, fl));  // needs r on the lower ghost plane
     if (kind == MG_RESTRICT_FULLW)
         launch_restrict_fw<T>(stream_, lv_[fl].g, lv_[fl + 1].g, ptr<T>(as, fl), ptr<T>(ad, fl + 1));
@@ -853,6 +972,7 @@ int Solver::prolong_t(int cl, int add, int as, int ad)
         set_last_error("transfer across the gather level is only available inside mg_cycle");
         return MG_ERR_BAD_ARG;
     }
+    if (ad == MG_ARR_RHS) lv_[cl - 1].rhs_halo_ok = false;
     MG_TRY(exchange(as, cl));  // odd fine planes read the coarse upper ghost plane
     launch_prolong<T>(stream_, lv_[cl].g, lv_[cl - 1].g, ptr<T>(as, cl), ptr<T>(ad, cl - 1), add != 0);
     MG_HIP(hipGetLastError());
@@ -883,6 +1003,7 @@ int Solver::correct(int arr_u, int arr_e)
 {
     if (!check_arr(arr_u, 0, "mg_correct") || !check_arr(arr_e, 0, "mg_correct") || arr_u == arr_e)
         return MG_ERR_BAD_ARG;
+    if (arr_u == MG_ARR_RHS || arr_e == MG_ARR_RHS) lv_[0].rhs_halo_ok = false;
     MG_HIP(hipSetDevice(device_));
     return d_.dtype == MG_F64 ? correct_t<double>(0, arr_u, arr_e) : correct_t<float>(0, arr_u, arr_e);
 }
@@ -992,14 +1113,20 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
     // fused residual + full weighting when both levels live whole on this rank
     const bool fuse_rr = mine && d_.restriction == MG_RESTRICT_FULLW && !lv_[l].dist && lv_[l + 1].present &&
                          resid_restrict_fast_ok<T>(lv_[l].g, lv_[l + 1].g);
+    // distributed level: the coarse slab is the next level's, or the staging slab when the next level is gathered
+    const Geom &gc_slab = lv_[l + 1].dist ? lv_[l + 1].g : stage_g_;
+    const bool fuse_rr_slab = mine && lv_[l].dist && d_.restriction == MG_RESTRICT_FULLW && depth2_enabled() &&
+                              resid_restrict_slab_ok<T>(lv_[l].g, gc_slab);
     const bool prof = profiling_ && l == 0 && mine;
     if (mine) {
         MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero, -1, true));
         if (prof) MG_TRY(prof_begin(l));
-        if (!fuse_rr) MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
+        if (!fuse_rr && !fuse_rr_slab) MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
     }
     if (lv_[l].dist && !lv_[l + 1].dist) {  // l == T_: restrict locally, gather the coarse rhs on rank 0
-        if (d_.restriction == MG_RESTRICT_FULLW) {
+        if (fuse_rr_slab) {
+            MG_TRY(resid_restrict_on_slab_t<T>(l, stage_g_, stageptr<T>(0)));
+        } else if (d_.restriction == MG_RESTRICT_FULLW) {
             MG_TRY(exchange(MG_ARR_TMP, l));
             launch_restrict_fw<T>(stream_, lv_[l].g, stage_g_, ptr<T>(MG_ARR_TMP, l), stageptr<T>(0));
         } else {
@@ -1019,7 +1146,10 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         MG_HIP(hipGetLastError());
         if (prof) MG_TRY(prof_end(l, MG_PROF_PROLONG, 1, 1));
     } else if (mine) {
-        if (fuse_rr) {
+        if (fuse_rr_slab) {
+            lv_[l + 1].rhs_halo_ok = false;
+            MG_TRY(resid_restrict_on_slab_t<T>(l, lv_[l + 1].g, ptr<T>(MG_ARR_RHS, l + 1)));
+        } else if (fuse_rr) {
             launch_resid_restrict_fw<T>(stream_, lv_[l].g, lv_[l + 1].g, coef_of<T>(lv_[l]), ptr<T>(MG_ARR_U, l),
                                         ptr<T>(MG_ARR_RHS, l), ptr<T>(MG_ARR_RHS, l + 1));
             MG_HIP(hipGetLastError());

@@ -41,6 +41,9 @@ struct Level {
     double coef[4] = {};
     bool present = true;         // false: level not held by this rank (gathered on rank 0)
     bool dist = false;           // true: z-slab of a level distributed over all ranks
+    int gh = 1;                  // ghost planes either side of the owned ones: 2 on distributed levels (one exchange then
+                                 // feeds a fused sweep pair / residual + restriction), 1 elsewhere (unused, zero)
+    bool rhs_halo_ok = false;    // distributed level: the RHS array's first ghost planes hold the neighbours' planes
     void *zebra = nullptr;       // MG_SMOOTH_ZEBRA_Y / _X: cp(j), den(j) of the line solve (2 * ny or 2 * nx values, device)
 };
 
@@ -81,6 +84,8 @@ public:
     int profile_get(int kind, double *ms, int *launches) const;
     int comm_info(int *rank, int *nranks, int *transport_ranks, const char **transport) const;
     size_t device_bytes() const { return bytes_; }
+    long long comm_groups() const { return comm_groups_; }
+    long long comm_bytes_sent() const { return comm_bytes_; }
 
     const mg_desc &desc() const { return d_; }
     int nlevels() const { return d_.levels; }
@@ -94,6 +99,9 @@ private:
                                        int corr_level = -1, bool e_scratch = false);
     template <typename T> bool can_fold_prolong(int level) const;
     template <typename T> int pair_on_slab_t(int level, bool rb);
+    template <typename T> int pair_on_slab2_t(int level, bool rb);   // depth-2 ghosts: one exchange, the fused kernel on the whole slab
+    template <typename T> int resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs);
+    int refresh_rhs_halo(int level);
     template <typename T> bool can_skip_zeroing(int level) const;
     template <typename T> int residual_t(int level, int ax, int ar, int arr_r, bool want_norm);
     template <typename T> int sumsq_t(int level, int arr);
@@ -104,8 +112,9 @@ private:
     // coarse "solve" of level l: persistent one-workgroup kernel, or -- when the level is too big
     // for one workgroup and the mode is MG_COARSE_FIXED -- coarse_maxit regular sweeps
     template <typename T> int coarse_level_t(int l, int ax, int ar);  // coarse solve of a still-distributed coarsest level, gathered
-    int exchange(int which, int level);          // ghost planes <-> z-neighbours (on the main stream)
-    int exchange_begin(int which, int level);    // the same on the comm stream, after the main stream's work so far
+    int exchange(int which, int level, int depth = 1);        // `depth` ghost planes <-> z-neighbours (on the main stream)
+    int exchange_begin(int which, int level, int depth = 1);  // the same on the comm stream, after the main stream's work so far
+    int halo_ops(int which, int level, int depth, P2POp *ops);
     int exchange_end();                          // main stream waits for the halo
     // Runs a stencil launch over a distributed level with the halo exchange of `arr_x` hidden
     // behind the interior planes: launch(sub-slab geometry, element offset of its first plane)
@@ -146,6 +155,8 @@ private:
     void *h_stage_ = nullptr;      // pinned staging buffer of set_array / get_array
     size_t h_stage_bytes_ = 0;
     bool overlap_ = true;  // MG_OVERLAP=0 disables (debugging)
+    long long comm_groups_ = 0, comm_bytes_ = 0;   // message groups posted / bytes sent by this rank (mg_comm_stats)
+    int post(const P2POp *ops, int n, hipStream_t s);  // comm_->batch + the counters
     int lock_iters_ = -1;  // >= 0: the next coarse solve runs exactly this many sweeps (lock-step parity mode)
     Geom gfull_{};
     void *full_[3] = {nullptr, nullptr, nullptr};

@@ -207,8 +207,10 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
     const long long ro_hi = (long long)min(2 * J0 + 2 * CR, gf.ny - 1) * gf.pitch + x0c;
     const T q = (T)0.25, h = (T)0.5;
 
-    // fine planes to evaluate (all inside the grid): 2K0-1 .. 2(K1-1)+1, or K0 .. K1-1 when z is kept
-    const int zs = SEMI ? K0 : max(2 * K0 - 1, 0), ze = SEMI ? K1 - 1 : min(2 * (K1 - 1) + 1, gf.nz - 1);
+    // fine planes to evaluate (all inside the GLOBAL grid): 2K0-1 .. 2(K1-1)+1, or K0 .. K1-1 when z is kept. On a z-slab
+    // (gf.gz0 > 0: the coarse slab starts at the fine slab's first plane) the first one is the lower ghost plane -1, whose
+    // residual needs u on plane -2: the caller exchanged two ghost planes of u and one of rhs.
+    const int zs = SEMI ? K0 : max(2 * K0 - 1, -gf.gz0), ze = SEMI ? K1 - 1 : min(2 * (K1 - 1) + 1, gf.nz - 1);
     vec um[NR], uc[NR], up[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) {
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
         uc[r] = *(const vec *)(u + (long long)zs * gf.plane + ro[r]);
     }
     {
-        const int sl = zs & 1;
+        const int sl = zs & 1;   // (-1 & 1 == 1: the parity of a ghost plane is as good as any other)
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             if (lane == 0) ued[sl][r][wv][0] = uc[r][0];
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
                 tlb[j] = rhs[i]; tlu[j] = u[i];
             }
         }
-        const bool zb = (z == 0) || (z == gf.nz - 1);
+        const int gzf = gf.gz0 + z;
+        const bool zb = (gzf == 0) || (gzf == gf.gnz - 1);
         vec res[NR];
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
         int emitK = -1;
         if (SEMI) emitK = z;                             // planes map one to one
         else if (z & 1) emitK = (z - 1) >> 1;            // z = 2K+1 closes coarse plane K
-        else if (z == gf.nz - 1) emitK = z >> 1;         // top boundary plane has no z+1: it injects
+        else if (gzf == gf.gnz - 1) emitK = z >> 1;      // top boundary plane of the grid has no z+1: it injects
         const bool centre = SEMI || !(z & 1);
 #pragma unroll
         for (int j = 0; j < CR; j++) {
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
                 if (tail_lane) ctr_tail[j] = tlb[j] - (T)1 * tlu[j];  // odd last fine column (Dirichlet): r = rhs - u
             }
             if (emitK >= K0 && emitK < K1 && J < gc.ny) {
-                const bool Kbnd = (emitK == 0) || (emitK == gc.nz - 1);
+                const bool Kbnd = (gc.gz0 + emitK == 0) || (gc.gz0 + emitK == gc.gnz - 1);
                 const bool Jbnd = (J == 0) || (J == gc.ny - 1);
                 const long long co = (long long)emitK * gc.plane + (long long)J * gc.pitch;
 #pragma unroll
@@ -403,6 +406,19 @@ bool resid_restrict_fast_ok(const Geom &gf, const Geom &gc)
            (gc.nx - 1 + 64 * (V / 2) - 1) / (64 * (V / 2)) <= 8;
 }
 
+// the same kernel on a z-slab of a distributed level: the coarse slab (the next level's, or the staging slab of the first
+// gathered level) holds the coarse planes that coincide with this rank's fine planes
+template <typename T>
+bool resid_restrict_slab_ok(const Geom &gf, const Geom &gc)
+{
+    constexpr int V = PV<T>::V;
+    const bool semi = transfer_is_semi(gf, gc);
+    const bool zok = semi ? (gf.nz == gc.nz && gf.gz0 == gc.gz0)
+                          : (gf.gz0 == 2 * gc.gz0 && (gf.nz == 2 * gc.nz || gf.nz == 2 * gc.nz - 1) && gf.gnz == 2 * gc.gnz - 1);
+    return gf.dim == 3 && gf.nx == 2 * gc.nx - 1 && gf.ny == 2 * gc.ny - 1 && zok && gc.nz >= 1 && gc.nx >= 17 && (gf.nx % V) == 1 &&
+           (gc.nx - 1 + 64 * (V / 2) - 1) / (64 * (V / 2)) <= 8;
+}
+
 template <typename T>
 void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, const Coef<T> &c, const T *u,
                               const T *rhs, T *coarse)
@@ -429,6 +445,8 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
     }
 }
 
+template bool resid_restrict_slab_ok<double>(const Geom &, const Geom &);
+template bool resid_restrict_slab_ok<float>(const Geom &, const Geom &);
 template bool resid_restrict_fast_ok<double>(const Geom &, const Geom &);
 template bool resid_restrict_fast_ok<float>(const Geom &, const Geom &);
 template void launch_resid_restrict_fw<double>(hipStream_t, const Geom &, const Geom &, const Coef<double> &, const double *, const double *, double *);

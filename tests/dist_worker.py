@@ -37,10 +37,14 @@ def main():
         from multigrid_prj_amd.dist import torch_host_comm
         s = capi.Solver(desc, device=0, rank=rank, nranks=world, host_comm=torch_host_comm())
         s.set_rhs(b)
-        for _ in range(cycles):
+        s.cycle()                      # the first cycle also sends the right-hand side's ghost planes once
+        g0, b0 = s.comm_stats()
+        for _ in range(cycles - 1):
             s.cycle()
+        g1, b1 = s.comm_stats()
         hist, _ = s.solve(0.0, 2)
         u = s.get_solution()
+        extra = dict(groups_per_cycle=(g1 - g0) / max(cycles - 1, 1), bytes_per_cycle=(b1 - b0) / max(cycles - 1, 1))
         if case.get("check_e"):
             # the public mg_smooth on a distributed level must leave the caller's E array alone (inside the
             # V-cycle the fused pair uses E as scratch; the API call may not) and still equal the fused result
@@ -52,6 +56,7 @@ def main():
             u = s.get_solution()
         s.close()
     else:
+        extra = {}
         from tests.slab_model import SlabVCycle
         m = SlabVCycle(desc, rank, world, dist)
         m.set_rhs(b)
@@ -59,7 +64,7 @@ def main():
             m.cycle()
         hist = m.solve_hist(2)
         u = m.solution()
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"), u=u, hist=np.asarray(hist), z0=z0, nz=nz, fg=fg)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), u=u, hist=np.asarray(hist), z0=z0, nz=nz, fg=fg, **extra)
     dist.barrier()
     dist.destroy_process_group()
 
