@@ -223,7 +223,11 @@ int Solver::init()
             if (rc) { set_last_error("mg_create_distributed: " + why); return rc; }
             T_ = p.first_gathered_level - 1;
             L.dist = l < p.first_gathered_level;
-            L.present = L.dist || rank_ == 0;
+            // Gathered levels: by default EVERY rank holds them and runs them redundantly (same bits everywhere) after an
+            // all-gather of the restricted right-hand side -- nobody waits for rank 0 to scatter the correction back, and
+            // rank 0 is no longer the one rank with more work. MG_REPLICATE_TAIL=0: rank 0 alone, gather + scatter.
+            replicate_ = [] { const char *e = getenv("MG_REPLICATE_TAIL"); return !(e && e[0] == '0'); }();
+            L.present = L.dist || rank_ == 0 || replicate_;
             if (L.dist) {
                 if (l == T_ && rank_ == 0 && T_ == d_.levels - 1) {  // coarsest level still distributed: rank 0 solves it gathered
                     gfull_ = L.g;
@@ -475,6 +479,19 @@ int Solver::gather_S(int arr)
     const size_t pb = (size_t)stage_g_.plane * esize();
     char *sb = reinterpret_cast<char *>(stage_base_[0]);
     int rc;
+    if (replicate_) {  // all-gather: my staging slab to everybody, everybody's into my full copy of the level
+        char *f = reinterpret_cast<char *>(L.base[arr]);
+        MG_HIP(hipMemcpyAsync(f + (size_t)(1 + planS_[rank_].z0) * pb, sb + pb, (size_t)stage_g_.nz * pb, hipMemcpyDeviceToDevice, stream_));
+        std::vector<P2POp> ops;
+        for (int r = 0; r < nranks_; r++) {
+            if (r == rank_) continue;
+            ops.push_back(P2POp{r, true, sb + pb, (size_t)stage_g_.nz * pb});
+            ops.push_back(P2POp{r, false, f + (size_t)(1 + planS_[r].z0) * pb, (size_t)planS_[r].nz * pb});
+        }
+        rc = post(ops.data(), (int)ops.size(), stream_);
+        if (rc) set_last_error("all-gather of the coarse right-hand side failed");
+        return rc;
+    }
     if (rank_ == 0) {
         char *f = reinterpret_cast<char *>(L.base[arr]);
         MG_HIP(hipMemcpyAsync(f + pb, sb + pb, (size_t)stage_g_.nz * pb, hipMemcpyDeviceToDevice, stream_));
@@ -498,6 +515,11 @@ int Solver::scatter_S(int arr)
     char *sb = reinterpret_cast<char *>(stage_base_[1]);
     auto planes = [&](int r) { return (size_t)planS_[r].nz + (r < nranks_ - 1 ? 1 : 0); };
     int rc;
+    if (replicate_) {  // every rank computed the level: its own planes (+ the upper ghost) are a local copy away
+        char *f = reinterpret_cast<char *>(L.base[arr]);
+        MG_HIP(hipMemcpyAsync(sb + pb, f + (size_t)(1 + planS_[rank_].z0) * pb, planes(rank_) * pb, hipMemcpyDeviceToDevice, stream_));
+        return MG_OK;
+    }
     if (rank_ == 0) {
         char *f = reinterpret_cast<char *>(L.base[arr]);
         MG_HIP(hipMemcpyAsync(sb + pb, f + pb, planes(0) * pb, hipMemcpyDeviceToDevice, stream_));
@@ -1135,7 +1157,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         MG_HIP(hipGetLastError());
         if (prof) MG_TRY(prof_end(l, MG_PROF_RESID_RESTRICT, 1, 2));
         MG_TRY(gather_S(MG_ARR_RHS));
-        if (rank_ == 0) {
+        if (lv_[l + 1].present) {
             const bool skip0 = can_skip_zeroing<T>(l + 1);
             if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
             MG_TRY(vcycle_rec_t<T>(l + 1, skip0));

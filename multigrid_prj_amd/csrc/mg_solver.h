@@ -155,6 +155,7 @@ private:
     void *h_stage_ = nullptr;      // pinned staging buffer of set_array / get_array
     size_t h_stage_bytes_ = 0;
     bool overlap_ = true;  // MG_OVERLAP=0 disables (debugging)
+    bool replicate_ = false;  // gathered levels are held and run by every rank (all-gather in, no scatter out)
     long long comm_groups_ = 0, comm_bytes_ = 0;   // message groups posted / bytes sent by this rank (mg_comm_stats)
     int post(const P2POp *ops, int n, hipStream_t s);  // comm_->batch + the counters
     int lock_iters_ = -1;  // >= 0: the next coarse solve runs exactly this many sweeps (lock-step parity mode)
