@@ -74,9 +74,10 @@ void Utils::parse_command_line(int argc, char **argv, Options &o)
             if (v <= 0) fail("Please, insert a valid level");
         } else if (a == "-smt" && has_value) {
             if (!parse_int(argv[i + 1], v)) fail("Please, insert a number after -smt");
-            o.smoother = static_cast<SMOOTHERS>(v);
-            std::cout << "Inserted Smoother number = " << o.smoother << std::endl;
-            if (o.smoother >= SMOOTHERS_END || v < 0) o.smoother = DEFAULT_METHOD;
+            // (the reference casts first and range-checks the enum afterwards -- undefined behaviour for a value
+            // outside the enumeration, flagged by UBSan; same echo line and same fallback here without it)
+            std::cout << "Inserted Smoother number = " << v << std::endl;
+            o.smoother = (v >= 0 && v < SMOOTHERS_END) ? static_cast<SMOOTHERS>(v) : DEFAULT_METHOD;
         } else if (a == "-test" && has_value) {
             if (!parse_int(argv[i + 1], v)) fail("Please, insert a double after -test");
             o.test = static_cast<int>(v);
