@@ -266,8 +266,10 @@ static int j2_nbz(const Geom &g)
 // half-sweep on the plane behind (black points updated from phase 1's values, red points
 // copied): out = RB(u) in one pass over HBM instead of two (k_sweep3d<OP_RB> twice).
 // ZEROU: u is identically zero (the two pre-smoothing sweeps of a coarse level): nothing is loaded for it.
-template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false, bool ZEROU = false, int TYO_ = J2_TYO>
-__global__ __launch_bounds__(TPR, 3) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
+// MINW: minimum waves per SIMD the register allocation is held to (3 = 168 VGPRs; 2 = 256: the fp32 folding variant spills otherwise)
+template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false, bool ZEROU = false, int TYO_ = J2_TYO,
+          int MINW = 3>
+__global__ __launch_bounds__(TPR, MINW) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
                                                  const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz,
                                                  const T *__restrict__ coarse, Geom gc)
 {
@@ -817,10 +819,19 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
     const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool damped = (omega != (T)1);
+    static const int minw_env = [] { const char *e = getenv("MG_J2C_MINW"); return e ? atoi(e) : 0; }();
+    // fp32 (four floats per lane, three coarse values per row) needs 180 VGPRs: held to 168 it spills 12 of them and runs
+    // 5.5 ms per launch at 1025^3; at two waves per SIMD, unspilled, 4.8 ms. fp64 fits 163.
+    const int minw = minw_env ? minw_env : (sizeof(T) == 4 ? 2 : 3);
 #define MG_J2C(TPR) \
     do { \
-        if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
-        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
+        if (minw == 2) { \
+            if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true, false, false, 2, 2>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
+            else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, false, false, 2, 2>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
+        } else { \
+            if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
+            else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
+        } \
     } while (0)
     switch (tpr) {
     case 512: MG_J2C(512); break;
