@@ -370,8 +370,9 @@ def main():
                            if world > 1 else None),
         "ms_per_step_with_residual_norm": solve_ms_per_cycle,
         "roofline": {"bound": "hbm",
-                     "kernel": (f"finest-grid fused double Jacobi sweep k_jacobi2 ({a.n}^3, two sweeps in one pass over HBM)" if fused_pair
-                                else f"finest-grid {a.smoother} sweep ({a.n}^3)"),
+                     "kernel": ((f"finest-grid fused double Jacobi sweep k_jacobi2 ({a.n}^3, two sweeps in one pass over HBM)" if fused_pair
+                                 else f"finest-grid {a.smoother} sweep ({a.n}^3)")
+                                + (f"; rank 0's z-slab of {nz} planes, one segment = halo exchange + interior + boundary launches" if world > 1 else "")),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "traffic_source": tr["source"] if tr else None,

@@ -244,6 +244,11 @@ int Solver::init()
                     for (int r = 0; r < nranks_; r++) plan_slab(d_, nranks_, r, l, &planT_[r], &why);
                 }
                 L.g.nz = p.nz; L.g.gz0 = p.z0;
+                L.nz_min = p.nz;
+                for (int r = 0; r < nranks_; r++) {
+                    SlabPlan q;
+                    if (plan_slab(d_, nranks_, r, l, &q, &why) == MG_OK) L.nz_min = std::min(L.nz_min, q.nz);
+                }
             }
         }
         if (nranks_ > 1 && l == T_ + 1 && l < d_.levels) {
@@ -264,6 +269,7 @@ int Solver::init()
                 bytes_ += nbytes;
             }
         }
+        if (!L.dist) L.nz_min = L.g.nz;
         L.gh = L.dist ? 2 : 1;
         L.alloc_elems = (size_t)(L.g.nz + 2 * L.gh) * (size_t)L.g.plane;
         if (!L.present) continue;
@@ -423,7 +429,7 @@ int Solver::exchange(int which, int level, int depth)
 {
     Level &L = lv_[level];
     if (!L.dist) return MG_OK;
-    if (depth > L.gh || depth > L.g.nz) { set_last_error("halo exchange deeper than the ghost planes / the slab"); return MG_ERR_BAD_ARG; }
+    if (depth > L.gh || depth > L.nz_min) { set_last_error("halo exchange deeper than the ghost planes / the thinnest slab"); return MG_ERR_BAD_ARG; }
     P2POp ops[4];
     const int n = halo_ops(which, level, depth, ops);
     int rc = post(ops, n, stream_);
@@ -434,7 +440,7 @@ int Solver::exchange(int which, int level, int depth)
 int Solver::exchange_begin(int which, int level, int depth)
 {
     Level &L = lv_[level];
-    if (depth > L.gh || depth > L.g.nz) { set_last_error("halo exchange deeper than the ghost planes / the slab"); return MG_ERR_BAD_ARG; }
+    if (depth > L.gh || depth > L.nz_min) { set_last_error("halo exchange deeper than the ghost planes / the thinnest slab"); return MG_ERR_BAD_ARG; }
     P2POp ops[4];
     const int n = halo_ops(which, level, depth, ops);
     MG_HIP(hipEventRecord(ev_ready_, stream_));
@@ -666,6 +672,16 @@ int Solver::pair_on_slab_t(int level, bool rb)
     return MG_OK;
 }
 
+// Every decision that changes WHICH messages a rank posts must come out the same on all ranks: the gates that look at
+// the slab's thickness are evaluated on the thinnest slab of the level, not on the local one (the last rank owns one
+// plane more, uneven splits differ by a coarse cell).
+static Geom slab_gate_geom(const Level &L)
+{
+    Geom g = L.g;
+    g.nz = L.nz_min;
+    return g;
+}
+
 static bool depth2_enabled()
 {
     static const bool e = [] { const char *v = getenv("MG_DEPTH2"); return !(v && v[0] == '0'); }();
@@ -769,7 +785,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
     switch (smoother) {
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
-            if (L.dist && depth2_enabled() && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps && jacobi2_slab_ok<T>(L.g)) {
+            if (L.dist && depth2_enabled() && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps && jacobi2_slab_ok<T>(slab_gate_geom(L))) {
                 if (x_zero && s == 0) {  // zero guess on every rank: no halo of u to fetch at all, only the neighbours' rhs planes
                     MG_TRY(refresh_rhs_halo(level));
                     launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level), true);
@@ -777,13 +793,13 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
                 } else {
                     MG_TRY(pair_on_slab2_t<T>(level, false));
                 }
-                s++; launches += 3;
+                s++; launches += 1;   // counted as ONE segment: exchange + interior + boundary launches
                 continue;
             }
             if (L.dist && overlap_ && e_scratch && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps &&
-                !(x_zero && s == 0) && jacobi2_slab_ok<T>(L.g)) {  // E is free in a V-cycle: scratch for the boundary planes' first sweep
+                !(x_zero && s == 0) && jacobi2_slab_ok<T>(slab_gate_geom(L))) {  // E is free in a V-cycle: scratch for the boundary planes' first sweep
                 MG_TRY(pair_on_slab_t<T>(level, false));
-                s++; launches += 5;
+                s++; launches += 1;
                 continue;
             }
             if (!L.dist && s + 1 < sweeps && jacobi2_ok<T>(L.g)) {
@@ -814,15 +830,15 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
         break;
     case MG_SMOOTH_RBGS:
         for (int s = 0; s < sweeps; s++) {
-            if (L.dist && depth2_enabled() && ax == MG_ARR_U && ar == MG_ARR_RHS && jacobi2_slab_ok<T>(L.g) && rb_slab_enabled()) {
+            if (L.dist && depth2_enabled() && ax == MG_ARR_U && ar == MG_ARR_RHS && jacobi2_slab_ok<T>(slab_gate_geom(L)) && rb_slab_enabled()) {
                 MG_TRY(pair_on_slab2_t<T>(level, true));   // one-pass red-black sweep on the whole slab, two ghost planes
-                launches += 3;
+                launches += 1;
                 continue;
             }
             if (L.dist && overlap_ && e_scratch && ax == MG_ARR_U && ar == MG_ARR_RHS &&
-                jacobi2_slab_ok<T>(L.g) && rb_slab_enabled()) {  // one-pass red-black sweep on the slab's inner planes
+                jacobi2_slab_ok<T>(slab_gate_geom(L)) && rb_slab_enabled()) {  // one-pass red-black sweep on the slab's inner planes
                 MG_TRY(pair_on_slab_t<T>(level, true));
-                launches += 5;
+                launches += 1;
                 continue;
             }
             if (!L.dist && rb_fused_ok<T>(L.g)) {  // both colours in one pass over HBM; the sweep lands in TMP

@@ -41,6 +41,7 @@ struct Level {
     double coef[4] = {};
     bool present = true;         // false: level not held by this rank (gathered on rank 0)
     bool dist = false;           // true: z-slab of a level distributed over all ranks
+    int nz_min = 0;              // thinnest slab of the level over all ranks (== g.nz when the level is not distributed)
     int gh = 1;                  // ghost planes either side of the owned ones: 2 on distributed levels (one exchange then
                                  // feeds a fused sweep pair / residual + restriction), 1 elsewhere (unused, zero)
     bool rhs_halo_ok = false;    // distributed level: the RHS array's first ghost planes hold the neighbours' planes
