@@ -1175,28 +1175,32 @@ __global__ __launch_bounds__(256) void k_zebra_y(Geom g, Coef<T> c, int colour, 
 
 // ---------------------------------------------------------------- zebra line Gauss-Seidel along x
 // One colour pass, lines along the FAST axis (EXTENSION), coloured by the parity of y (+ z). A thread
-// marching along its own line would use 8 bytes of every 128-byte line it touches, so a workgroup of ZXT threads takes
-// ZXT lines of the active colour and walks them in chunks of XC = 256 B / sizeof(T) columns:
-//   (A) all threads together evaluate R = b - S on the ZXT x XC tile -- 32 (64) consecutive lanes per line segment, so
-//       every access is two whole aligned 128-byte lines -- into LDS;
-//   (B) thread t runs the elimination recurrence of line t over the chunk's columns out of LDS (rows padded to an odd
+// marching along its own line would use 8 bytes of every 128-byte line it touches, so ONE WAVE takes 64 lines of the
+// active colour and walks them in chunks of XC = 8 columns (one 64-byte segment per line in fp64):
+//   (A) the 64 lanes together evaluate R = b - S on the 64 x XC tile -- 8 consecutive lanes per line segment, so
+//       every access is a whole aligned segment -- into LDS; the operands of chunk c+1 are loaded into registers
+//       while chunk c's recurrence runs (they are consumed before the next prefetch overwrites them);
+//   (B) lane l runs the elimination recurrence of line l over the chunk's columns out of LDS (rows padded to an odd
 //       stride: conflict-free), carrying dp(x-1) in a register from chunk to chunk;
 //   (C) the tile goes to the dp scratch array, coalesced again.
 // The back substitution walks the chunks in reverse the same way. Per line the operations and their order are those of
-// the CPU restatement's sequential Thomas solve => same bits; lines never cross a z-slab.
-constexpr int ZXT = 128;
+// the CPU restatement's sequential Thomas solve => same bits; lines never cross a z-slab. (History: 256-line workgroups
+// with the loads inside the tile loop 1.06 ms per colour pass at 513^3, batched loads and LDS-staged factors 1.0 ms --
+// both latency-bound by their load / recurrence / store phases at two waves per SIMD; this one-wave pipeline: see DESIGN.md.)
+constexpr int ZXT = 64;
 
 template <typename T, int DIM>
 __global__ __launch_bounds__(ZXT) void k_zebra_x(Geom g, Coef<T> c, int colour, T *__restrict__ u, const T *__restrict__ rhs,
                                                  T *__restrict__ dp, const T *__restrict__ cp, const T *__restrict__ den,
                                                  int lpp, int nlines)
 {
-    constexpr int XC = 256 / (int)sizeof(T), LP = XC + 1;  // two 128-byte lines per line and chunk
-    constexpr int UB = 8;                                   // tile points per thread whose loads are issued together
+    constexpr int XC = 8, LP = XC + 1;                    // columns per chunk (64-byte segments in fp64, 32-byte in fp32: 16 columns
+                                                          // would need 197 VGPRs there); tile points per lane = XC
+    constexpr int LPL = ZXT / XC;                         // lines covered by one wave-wide access
     __shared__ T tile[ZXT][LP];
     __shared__ long long lbase[ZXT];
     __shared__ int lflag[ZXT];  // 0: no such line, 1: interior line, 2: line inside the boundary (identity rows)
-    __shared__ T sfac[XC];      // den(x) / cp(x) of the chunk: read inside the recurrence, so they must not come from global memory there
+    __shared__ T sfac[XC];      // den(x) / cp(x) of the chunk
     const int t = threadIdx.x;
     {
         const int L = blockIdx.x * ZXT + t;  // line slot: z = L / lpp, y = 2 (L % lpp) + parity
@@ -1209,96 +1213,117 @@ __global__ __launch_bounds__(ZXT) void k_zebra_x(Geom g, Coef<T> c, int colour, 
         lflag[t] = active ? (bnd ? 2 : 1) : 0;
     }
     __syncthreads();
+    // LDS-only release / acquire around the barrier: a full __syncthreads() also waits for every outstanding global load,
+    // i.e. for the prefetch of the next chunk that was just issued
+    auto lds_barrier = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
     const int nx = g.nx, nch = (nx + XC - 1) / XC;
     const int myflag = lflag[t];
-    // tile point q of this thread: q-th group of ZXT consecutive points, XC consecutive points per line
-    auto line_of = [&](int q) { return (q * ZXT + t) / XC; };
-    auto col_of = [&](int q) { return (q * ZXT + t) % XC; };
-    T carry = 0;  // dp(x-1) of the thread's own line
+    // this lane's tile points: column col of lines l0 + LPL * q, q = 0 .. XC-1
+    const int col = t % XC, l0 = t / XC;
+    long long pb[XC];   // element offset of (line, column 0) for the lane's XC lines
+    int pf[XC];
+#pragma unroll
+    for (int q = 0; q < XC; q++) { pb[q] = lbase[l0 + LPL * q]; pf[q] = lflag[l0 + LPL * q]; }
+
+    T b[XC], um[XC], up[XC], zm[XC], zp[XC], fac = 0;
+    auto load_chunk = [&](int ch) {   // operands of chunk ch: only loads
+        const int x = ch * XC + col;
+        const int xc_ = min(x, nx - 1);
+        const bool xin = x < nx, xinner = x > 0 && x < nx - 1;
+#pragma unroll
+        for (int q = 0; q < XC; q++) {
+            const long long idx = pb[q] + xc_;
+            const bool inner = pf[q] == 1 && xinner;
+            b[q] = (pf[q] && xin) ? rhs[idx] : (T)0;
+            um[q] = inner ? u[idx - g.pitch] : (T)0;
+            up[q] = inner ? u[idx + g.pitch] : (T)0;
+            zm[q] = (DIM == 3 && inner) ? u[idx - g.plane] : (T)0;
+            zp[q] = (DIM == 3 && inner) ? u[idx + g.plane] : (T)0;
+        }
+        fac = den[min(ch * XC + col, nx - 1)];
+    };
+    T carry = 0;  // dp(x-1) of the lane's own line
+    load_chunk(0);
     for (int ch = 0; ch < nch; ch++) {
         const int x0 = ch * XC, ncol = min(XC, nx - x0);
-        if (t < XC) sfac[t] = den[min(x0 + t, nx - 1)];
-        for (int q0 = 0; q0 < XC; q0 += UB) {  // (A): UB points at a time, every load of the batch before its arithmetic
-            T b[UB], um[UB], up[UB], zm[UB], zp[UB];
-            int fl[UB];
+        {   // (A) from the registers loaded one chunk ago
+            const int x = x0 + col;
+            const bool xinner = x > 0 && x < nx - 1;
 #pragma unroll
-            for (int k = 0; k < UB; k++) {
-                const int ll = line_of(q0 + k), x = x0 + col_of(q0 + k);
-                fl[k] = (x < nx) ? lflag[ll] : 0;
-                const long long idx = lbase[ll] + min(x, nx - 1);
-                const bool inner = fl[k] == 1 && x > 0 && x < nx - 1;
-                b[k] = fl[k] ? rhs[idx] : (T)0;
-                um[k] = inner ? u[idx - g.pitch] : (T)0;
-                up[k] = inner ? u[idx + g.pitch] : (T)0;
-                zm[k] = (DIM == 3 && inner) ? u[idx - g.plane] : (T)0;
-                zp[k] = (DIM == 3 && inner) ? u[idx + g.plane] : (T)0;
-                if (!inner) fl[k] = fl[k] ? 2 : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < UB; k++) {
-                T R = b[k];
-                if (fl[k] == 1) {
+            for (int q = 0; q < XC; q++) {
+                T R = b[q];
+                if (pf[q] == 1 && xinner) {
                     T S = 0;
-                    if (DIM == 3) S += c.cz * zm[k];
-                    S += c.cy * um[k];
-                    S += c.cy * up[k];
-                    if (DIM == 3) S += c.cz * zp[k];
+                    if (DIM == 3) S += c.cz * zm[q];
+                    S += c.cy * um[q];
+                    S += c.cy * up[q];
+                    if (DIM == 3) S += c.cz * zp[q];
                     R = R - S;
                 }
-                tile[line_of(q0 + k)][col_of(q0 + k)] = R;
+                tile[l0 + LPL * q][col] = R;
             }
+            if (t < XC) sfac[t] = fac;   // lanes 0 .. XC-1 have col == t
         }
-        __syncthreads();
+        lds_barrier();
+        if (ch + 1 < nch) load_chunk(ch + 1);   // in flight during the recurrence and the store below
         if (myflag == 1) {  // (B) dp(0) = b(0); dp(x) = (R(x) - cx dp(x-1)) / den(x); the last column keeps b(nx-1)
-#pragma unroll 8
-            for (int col = 0; col < XC; col++) {
-                const int x = x0 + col;
-                const T r = tile[t][col];
-                T nc = (r - c.cx * carry) / sfac[col];
+#pragma unroll
+            for (int k = 0; k < XC; k++) {
+                const int x = x0 + k;
+                const T r = tile[t][k];
+                T nc = (r - c.cx * carry) / sfac[k];
                 if (x == 0 || x == nx - 1) nc = r;
-                if (col < ncol) { carry = nc; tile[t][col] = nc; }
+                if (k < ncol) { carry = nc; tile[t][k] = nc; }
             }
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int q = 0; q < XC; q++) {  // (C)
-            const int ll = line_of(q), col = col_of(q), x = x0 + col;
-            if (lflag[ll] && x < nx) dp[lbase[ll] + x] = tile[ll][col];
+        lds_barrier();
+        {   // (C)
+            const int x = x0 + col;
+#pragma unroll
+            for (int q = 0; q < XC; q++)
+                if (pf[q] && x < nx) dp[pb[q] + x] = tile[l0 + LPL * q][col];
         }
-        __syncthreads();
+        lds_barrier();
     }
     // back substitution: u(nx-1) = b(nx-1); u(x) = dp(x) - cp(x) u(x+1); u(0) = dp(0)
+    __syncthreads();   // the dp stores of the forward pass are read back by other lanes: global memory ordered here
+    T d[XC];
+    auto load_back = [&](int ch) {
+        const int x = ch * XC + col;
+#pragma unroll
+        for (int q = 0; q < XC; q++) d[q] = (pf[q] && x < nx) ? dp[pb[q] + x] : (T)0;
+        fac = cp[min(x, nx - 1)];
+    };
+    load_back(nch - 1);
     for (int ch = nch - 1; ch >= 0; ch--) {
         const int x0 = ch * XC, ncol = min(XC, nx - x0);
-        if (t < XC) sfac[t] = cp[min(x0 + t, nx - 1)];
-        for (int q0 = 0; q0 < XC; q0 += UB) {
-            T v[UB];
 #pragma unroll
-            for (int k = 0; k < UB; k++) {
-                const int ll = line_of(q0 + k), x = x0 + col_of(q0 + k);
-                v[k] = (lflag[ll] && x < nx) ? dp[lbase[ll] + x] : (T)0;
-            }
-#pragma unroll
-            for (int k = 0; k < UB; k++) tile[line_of(q0 + k)][col_of(q0 + k)] = v[k];
-        }
-        __syncthreads();
+        for (int q = 0; q < XC; q++) tile[l0 + LPL * q][col] = d[q];
+        if (t < XC) sfac[t] = fac;
+        lds_barrier();
+        if (ch > 0) load_back(ch - 1);
         if (myflag == 1) {
-#pragma unroll 8
-            for (int col = XC - 1; col >= 0; col--) {
-                const int x = x0 + col;
-                const T d = tile[t][col];
-                T nc = d - sfac[col] * carry;
-                if (x == 0 || x == nx - 1) nc = d;
-                if (col < ncol) { carry = nc; tile[t][col] = nc; }
+#pragma unroll
+            for (int k = XC - 1; k >= 0; k--) {
+                const int x = x0 + k;
+                const T dd = tile[t][k];
+                T nc = dd - sfac[k] * carry;
+                if (x == 0 || x == nx - 1) nc = dd;
+                if (k < ncol) { carry = nc; tile[t][k] = nc; }
             }
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int q = 0; q < XC; q++) {
-            const int ll = line_of(q), col = col_of(q), x = x0 + col;
-            if (lflag[ll] && x < nx) u[lbase[ll] + x] = tile[ll][col];
+        lds_barrier();
+        {
+            const int x = x0 + col;
+#pragma unroll
+            for (int q = 0; q < XC; q++)
+                if (pf[q] && x < nx) u[pb[q] + x] = tile[l0 + LPL * q][col];
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
