@@ -115,3 +115,49 @@ def test_slab_plan_single_rank_and_errors():
         capi.plan_slab(d, 64, 0, 0)  # too many ranks for the grid
     with pytest.raises(capi.MgError):
         capi.plan_slab(capi.make_desc(dim=2, n=65, levels=3), 2, 0, 0)
+
+
+def test_slab_plan_invariants_over_random_hierarchies():
+    """Property test of the host-only partition plan (hypothesis): for any admissible (n, levels, semi_xy, ranks,
+    dist_min_n) every distributed level is covered exactly once in rank order, every rank keeps at least two planes,
+    coarse plane K lives with the fine plane it coincides with (2K, or K across a semi-coarsening), all ranks agree on the
+    first gathered level, and gathered levels belong to rank 0 in the plan."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=300, deadline=None)
+    @given(m=st.integers(2, 9), levels=st.integers(1, 7), nranks=st.integers(1, 8), semi=st.integers(0, 3),
+           dmin=st.sampled_from([0, 9, 17, 33, 65, 129]))
+    def check(m, levels, nranks, semi, dmin):
+        n = m * 2 ** (levels - 1) + 1
+        if n < 3 or n > 1100:
+            return
+        semi = min(semi, levels - 1)
+        d = capi.make_desc(dim=3, n=n, levels=levels, semi_xy=semi, dist_min_n=dmin,
+                           aniso=(1.0, 1.0, 0.1 if semi else 1.0))
+        try:
+            plans = [[capi.plan_slab(d, nranks, r, l) for r in range(nranks)] for l in range(levels)]
+        except capi.MgError:
+            assert nranks > 1          # refused: too many ranks for this grid
+            return
+        fg = plans[0][0][2]
+        assert 1 <= fg <= levels
+        for l in range(levels):
+            nz_l = n if l <= semi else ((n - 1) >> (l - semi)) + 1
+            assert all(p[2] == fg for p in plans[l])
+            if l >= fg:
+                assert plans[l][0][:2] == (0, nz_l) and all(p[:2] == (0, 0) for p in plans[l][1:])
+                continue
+            covered = 0
+            for r, (z0, nz, _) in enumerate(plans[l]):
+                assert z0 == covered and nz >= (2 if nranks > 1 else 1)
+                covered += nz
+            assert covered == nz_l
+            if l + 1 < fg:
+                keep_z = l < semi            # the transition l -> l+1 keeps z
+                for r in range(nranks):
+                    z0f, nzf, _ = plans[l][r]
+                    z0c, nzc, _ = plans[l + 1][r]
+                    assert z0f == (z0c if keep_z else 2 * z0c)
+                    assert nzf in ((nzc,) if keep_z else (2 * nzc, 2 * nzc - 1))
+
+    check()
