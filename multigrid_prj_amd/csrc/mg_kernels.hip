@@ -826,9 +826,13 @@ __device__ __forceinline__ double wave_sum_dpp(double v)
     return __hiloint2double(hi, lo);
 }
 
+// (runs of 7 / 8 points need more than the 128 VGPRs a 1024-thread workgroup leaves: those variants are limited to 512
+// threads -- 504 at 65^2, 450 at 17^3 -- and spill nothing)
+template <int SEG> struct CoarseRowsThreads { static constexpr int value = SEG >= 7 ? 512 : SWG; };
+
 template <typename T, int DIM, int SEG>
-__global__ __launch_bounds__(SWG) void k_coarse_jacobi_rows(Geom g, Coef<T> c, T omega, T *x, const T *rhs,
-                                                            int maxit, double tol, int fixed, CoarseOut *out)
+__global__ __launch_bounds__(CoarseRowsThreads<SEG>::value) void k_coarse_jacobi_rows(Geom g, Coef<T> c, T omega, T *x, const T *rhs,
+                                                            int maxit, double tol, int fixed, CoarseOut *out, int skip)
 {
     // Threads own INTERIOR points only, in full runs of SEG:
     // the iteration body has no predicates and no boundary selects, so the SEG points of a thread
@@ -840,6 +844,7 @@ __global__ __launch_bounds__(SWG) void k_coarse_jacobi_rows(Geom g, Coef<T> c, T
     const int nx = g.nx, ny = g.ny, npl = nx * ny, total = npl * g.nz;
     T *cur = reinterpret_cast<T *>(smem_raw);
     T *nxt = cur + total;
+    T *chk = cur + 2 * total;  // (skip > 1 only) the iterate the current window of unchecked sweeps started from
     const int W = nx - 2, nseg = (W + SEG - 1) / SEG;
     const int irows = (ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
     const int nthr = (int)blockDim.x;
@@ -905,8 +910,45 @@ __global__ __launch_bounds__(SWG) void k_coarse_jacobi_rows(Geom g, Coef<T> c, T
         }
         return sqrt(nr / nb) > tol;  // NaN (zero rhs) compares false, like the reference
     };
+    // Checking the norm only every `skip` sweeps. The Jacobi iteration matrix of this operator (constant diagonal, identity
+    // Dirichlet rows) is symmetric with spectrum inside (-1, 1), so the residual's 2-norm never grows from one sweep to the
+    // next: if Norm() > tol holds at sweep k + skip it held at every sweep in between, and the reference's loop (one test
+    // per sweep, solvers.hpp:324-342) would not have stopped there either. So: after an accepted, checked sweep save the
+    // iterate, run skip-1 sweeps WITHOUT residual, norm and reduction (about half the work of a checked one), check again;
+    // the first time the test says stop inside a window, go back to the saved iterate and walk the window one checked sweep
+    // at a time -- the stopping sweep, the flag and the iterate are exactly the reference's. Fixed-sweep mode needs no test
+    // at all until the last sweep.
+    auto fast_sweep = [&]() {   // x <- J x : no residual, no norm; one barrier
+        if (active) {
+            const T el = cur[i0 - 1], er = cur[i0 + SEG];
+            T num[SEG], quo[SEG];
+#pragma unroll
+            for (int k = 0; k < SEG; k++) {
+                const T left = (k == 0) ? el : xv[k > 0 ? k - 1 : 0];
+                const T right = (k == SEG - 1) ? er : xv[k < SEG - 1 ? k + 1 : 0];
+                T os = 0;
+                if (DIM == 3) os += c.cz * cur[i0 + k - npl];
+                os += c.cy * cur[i0 + k - nx];
+                os += c.cx * left;
+                os += c.cx * right;
+                os += c.cy * cur[i0 + k + nx];
+                if (DIM == 3) os += c.cz * cur[i0 + k + npl];
+                num[k] = bv[k] - os;
+            }
+            div_cd_n<T, SEG>(num, quo, c);
+#pragma unroll
+            for (int k = 0; k < SEG; k++) {
+                xv[k] = damped ? xv[k] + omega * (quo[k] - xv[k]) : quo[k];
+                nxt[i0 + k] = xv[k];
+            }
+        }
+        __syncthreads();
+        T *t_ = cur; cur = nxt; nxt = t_;
+    };
     int iters = 0, flag = 0, counter = maxit;
     double nr, bnd_sq = 0.;  // bnd_sq: this thread's share of the Dirichlet nodes' r^2 (constant from trip 2 on)
+    int iters_chk = 0;
+    bool in_window = false, stepping = false;   // in_window: the last skip-1 sweeps were not checked; stepping: re-walking a window
     for (;;) {
         double sq = 0.;
         if (iters < 2) {  // uniform. Dirichlet nodes: r = b - 1*x, x <- b
@@ -970,12 +1012,34 @@ __global__ __launch_bounds__(SWG) void k_coarse_jacobi_rows(Geom g, Coef<T> c, T
         if (fixed) go = iters < maxit;
         else if (above_tol(nr)) { go = counter > 0; if (!go) flag = 1; }
         else go = false;
-        if (!go) break;  // uniform: every thread sees the same nr
+        if (!go) {  // uniform: every thread sees the same nr
+            if (!in_window) break;
+            // the stop lies somewhere in the unchecked window: back to its first iterate, then one checked sweep at a time
+            for (int q = tid; q < total; q += nthr) cur[q] = chk[q];
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < SEG; k++) xv[k] = chk[i0 + k];
+            }
+            counter += iters - iters_chk; iters = iters_chk; flag = 0;
+            in_window = false; stepping = true;
+            __syncthreads();
+            continue;
+        }
         counter -= 1;
         iters++;
 #pragma unroll
         for (int k = 0; k < SEG; k++) xv[k] = nv[k];
         T *t = cur; cur = nxt; nxt = t;
+        in_window = false;
+        if (fixed) {   // no test until the end: after the two trips that settle the Dirichlet nodes in both buffers, every remaining sweep unchecked
+            if (iters >= 2) while (iters < maxit) { fast_sweep(); iters++; counter--; }
+        } else if (skip > 1 && !stepping && iters >= 2 && counter > skip) {
+            for (int q = tid; q < total; q += nthr) chk[q] = cur[q];
+            iters_chk = iters;
+            __syncthreads();
+            for (int s_ = 0; s_ < skip - 1; s_++) { fast_sweep(); iters++; counter--; }
+            in_window = true;
+        }
     }
     // cur holds the final iterate, Dirichlet nodes included
     for (int q = tid; q < total; q += nthr) x[dense_to_global(q)] = cur[q];
@@ -1522,11 +1586,15 @@ static bool try_launch_coarse_jacobi_rows(hipStream_t s, const Geom &g, const Co
                                           const T *rhs, int maxit, double tol, int fixed, CoarseOut *d_out)
 {
     const size_t total = (size_t)g.nx * g.ny * g.nz;
-    const size_t bytes = 2 * total * sizeof(T);
+    // MG_COARSE_SKIP = sweeps between two norm tests (1 = test after every sweep, the plain loop)
+    static const int skip_env = [] { const char *e = getenv("MG_COARSE_SKIP"); return e ? atoi(e) : 8; }();
+    int skip = skip_env < 1 ? 1 : skip_env;
+    if (3 * total * sizeof(T) > (size_t)150 * 1024) skip = 1;   // no room for the window's first iterate
+    const size_t bytes = (skip > 1 ? 3 : 2) * total * sizeof(T);
     const int W = g.nx - 2, nseg = (W + SEG - 1) / SEG;
     if (W < SEG || nseg * SEG - W > 1) return false;  // full runs, at most one shared point per row
     const int threads = nseg * (g.ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
-    if (threads < 128 || threads > SWG || bytes > (size_t)150 * 1024) return false;
+    if (threads < 128 || threads > CoarseRowsThreads<SEG>::value || bytes > (size_t)150 * 1024) return false;
     auto kern = k_coarse_jacobi_rows<T, DIM, SEG>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -1534,7 +1602,7 @@ static bool try_launch_coarse_jacobi_rows(hipStream_t s, const Geom &g, const Co
                                 150 * 1024) != hipSuccess) return false;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(((threads + 63) / 64) * 64), bytes, s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(((threads + 63) / 64) * 64), bytes, s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, skip);
     return true;
 }
 
@@ -1554,7 +1622,7 @@ static bool try_launch_coarse_jacobi(hipStream_t s, const Geom &g, const Coef<T>
     for (int seg : (DIM == 3 ? order3 : order2)) {
         if (seg != 4 && seg != 5 && seg != 7 && seg != 8) continue;
         const int nseg = (W + seg - 1) / seg, threads = nseg * irows;
-        if (W < seg || nseg * seg - W > 1 || threads < 128 || threads > SWG) continue;
+        if (W < seg || nseg * seg - W > 1 || threads < 128 || threads > (seg >= 7 ? 512 : SWG)) continue;
         best = seg;
         break;
     }
