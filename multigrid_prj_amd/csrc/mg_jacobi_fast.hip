@@ -610,13 +610,13 @@ __global__ __launch_bounds__(TPR, MINW) void k_jacobi2(Geom g, Coef<T> c, T omeg
 
 struct FastGrid { int nbx, nby, nbz, grid; };
 template <typename T>
-FastGrid fast_grid(const Geom &g)
+FastGrid fast_grid(const Geom &g, int zc = ZC)
 {
     constexpr int V = VecOf<T>::V;
     FastGrid f;
     f.nbx = (g.nx / V + 63) / 64;
     f.nby = (g.ny + RY * BW - 1) / (RY * BW);
-    f.nbz = (g.nz + ZC - 1) / ZC;
+    f.nbz = (g.nz + zc - 1) / zc;
     // small levels (<= 65^3 in fp64) are latency-bound: every marched plane is one more dependent memory round trip
     // and the grid does not fill the chip anyway -- one plane per workgroup there (7.8 -> ~5 us per sweep at 65^3)
     if (f.nbx * f.nby * f.nbz < 1024) f.nbz = g.nz;
@@ -679,7 +679,10 @@ template <typename T>
 int launch_residual_fast(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs,
                          T *r, double *d_partials, bool want_norm)
 {
-    FastGrid f = fast_grid<T>(g);
+    // the norm-only residual writes nothing, so longer marches (fewer z-halo planes re-read) only help it: 9 planes
+    // 0.458 ms at 513^3 against 0.51 with 3, 0.48 with 6, 0.464 with 12 (MG_RES_ZC)
+    static const int res_zc = [] { const char *e = getenv("MG_RES_ZC"); return e ? atoi(e) : 9; }();
+    FastGrid f = fast_grid<T>(g, (!r && want_norm && res_zc > 0) ? res_zc : ZC);
     const bool nt = stream_level(g, sizeof(T));
     dim3 gr(f.grid), bl(64 * BW);
 #define MG_R(S, NO, N) hipLaunchKernelGGL((k_sweep3d<T, OP_RESIDUAL, false, S, NO, N>), gr, bl, 0, s, g, c, (T)1, 0, u, rhs, r, d_partials, f.nbx, f.nby, f.nbz)
