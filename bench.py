@@ -64,6 +64,9 @@ def parse(argv=None):
     ap.add_argument("--transport", choices=["rccl", "gloo"], default="rccl",
                     help="N>1 halo transport: rccl = GPU-to-GPU over xGMI (one GPU per rank, the real thing); "
                          "gloo = rehearsal through host memory, ranks may share a GPU (numbers meaningless)")
+    ap.add_argument("--dry-rank", type=int, default=-1,
+                    help="MEASUREMENT TOOL, one process, one GPU: run rank R of --gpus N with no peers (every exchange is a "
+                         "no-op, results meaningless) to time that rank's compute schedule; the line is marked dry_run")
     ap.add_argument("--dist-min-n", type=int, default=0, help="mg_desc.dist_min_n (0 = library default)")
     ap.add_argument("--aniso-y", type=float, default=1.0, help="y-coupling multiplier of -(dxx + a dyy + dzz)")
     ap.add_argument("--aniso-x", type=float, default=1.0, help="x-coupling multiplier of -(a dxx + dyy + dzz)")
@@ -204,11 +207,14 @@ def rehearse(a, rank, world):
 def main():
     argv = sys.argv[1:]
     a = parse(argv)
-    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and a.gpus > 1:
+    dry = a.dry_rank >= 0 and a.gpus > 1
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and a.gpus > 1 and not dry:
         sys.exit(launch(a, argv))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if dry:
+        rank, world, local_rank = a.dry_rank, a.gpus, 0
     if world != a.gpus:
         a.gpus = world   # under torch.distributed.run the environment is authoritative
     if world > 1:
@@ -225,7 +231,7 @@ def main():
     comm_id = None
     host_comm = None
     device = local_rank
-    if world > 1:
+    if world > 1 and not dry:
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -242,7 +248,7 @@ def main():
             host_comm = torch_host_comm()
 
     desc = workload_desc(capi, a)
-    s = capi.Solver(desc, device=device, rank=rank, nranks=world, comm_id=comm_id, host_comm=host_comm)
+    s = capi.Solver(desc, device=device, rank=rank, nranks=world, comm_id=comm_id, host_comm=host_comm, dry=dry)
     z0, nz, first_gathered = capi.plan_slab(desc, world, rank, 0)
     npdt = np.float64 if a.dtype == "f64" else np.float32
     s.set_rhs(hash_rhs(a.n, npdt, z0, nz))
@@ -363,6 +369,7 @@ def main():
                                   f"coarse {((a.n - 1) >> (a.levels - 1)) + 1}^3 iterated to rel. residual 0.1, {a.dtype}"),
                    "parallelism": (f"z-slab x{world}" + ("" if a.transport == "rccl" else " (gloo rehearsal)")) if world > 1 else "single GPU",
                    "first_gathered_level": first_gathered},
+        **({"dry_run": f"rank {rank} of {world} WITHOUT communication: one rank's compute schedule, not a result"} if dry else {}),
         "transport": transport_name, "rccl_ranks": transport_ranks if transport_name == "rccl" else None,
         "ms_per_step_ranks": per_rank_ms,
         # what rank 0 posts per cycle: message groups (halo exchanges, gather, scatter: one ncclGroup each) and bytes sent
@@ -396,7 +403,7 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)
-    if rank == 0:
+    if rank == 0 or dry:
         print(json.dumps(out))
     s.close()
     if dist is not None:

@@ -198,6 +198,10 @@ typedef struct mg_host_comm {
 } mg_host_comm;
 int mg_create_distributed_hostcomm(const mg_desc *desc, int device, int rank, int nranks,
                                    const mg_host_comm *comm, mg_handle *out);
+/* MEASUREMENT ONLY: rank `rank` of `nranks` with no peers -- every exchange and all-reduce is a no-op, so the
+ * results are meaningless; the handle runs one rank's launch schedule (slab kernels, boundary launches, replicated
+ * coarse levels) so that its compute time can be measured on a single GPU (bench.py --transport dry). */
+int mg_create_distributed_dryrun(const mg_desc *desc, int device, int rank, int nranks, mg_handle *out);
 /* host-only partition plan (no GPU needed): z-planes [z0, z0+nz) of level l owned by
  * rank r, and the first level that is agglomerated on rank 0 */
 int mg_plan_slab(const mg_desc *desc, int nranks, int rank, int level, int *z0, int *nz,

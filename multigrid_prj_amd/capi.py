@@ -89,7 +89,7 @@ EXPORTS = [
     "mg_get_array", "mg_zero_array", "mg_smooth", "mg_residual", "mg_sumsq", "mg_restrict",
     "mg_prolong", "mg_correct", "mg_coarse_solve", "mg_coarse_solve_ex", "mg_cycle", "mg_cycle_async", "mg_solve", "mg_solve_lockstep",
     "mg_set_stage_callback", "mg_sync", "mg_timer_start", "mg_timer_stop", "mg_profile_begin", "mg_profile_end", "mg_profile_fused", "mg_profile_get", "mg_comm_info", "mg_comm_stats", "mg_device_bytes", "mg_comm_unique_id", "mg_comm_selftest",
-    "mg_create_distributed", "mg_create_distributed_hostcomm", "mg_plan_slab",
+    "mg_create_distributed", "mg_create_distributed_hostcomm", "mg_create_distributed_dryrun", "mg_plan_slab",
 ]
 
 _lib = None
@@ -147,6 +147,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.mg_comm_selftest.argtypes = [C.c_size_t]
     L.mg_create_distributed.argtypes = [C.POINTER(MgDesc), i, i, i, vp, C.POINTER(vp)]
     L.mg_create_distributed_hostcomm.argtypes = [C.POINTER(MgDesc), i, i, i, C.POINTER(MgHostComm), C.POINTER(vp)]
+    L.mg_create_distributed_dryrun.argtypes = [C.POINTER(MgDesc), i, i, i, C.POINTER(vp)]
     L.mg_plan_slab.argtypes = [C.POINTER(MgDesc), i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     _lib = L
     return L
@@ -186,14 +187,16 @@ class Solver:
     (`x * smoother`, `x * RES`, interpolate, Solve, SawtoothMGIteration, main loop)."""
 
     def __init__(self, desc: MgDesc, device: int = -1, rank: int = 0, nranks: int = 1, comm_id: bytes | None = None,
-                 host_comm: "MgHostComm | None" = None):
+                 host_comm: "MgHostComm | None" = None, dry: bool = False):
         self.lib = load()
         self.d = desc
         self.np = np.float64 if desc.dtype == MG_F64 else np.float32
         self.h = C.c_void_p()
         self.rank, self.nranks = rank, nranks
         self._host_comm = host_comm  # keep the callbacks alive
-        if nranks > 1 and host_comm is not None:
+        if nranks > 1 and dry:   # measurement only: no peers, nothing moves
+            _check(self.lib.mg_create_distributed_dryrun(C.byref(desc), device, rank, nranks, C.byref(self.h)))
+        elif nranks > 1 and host_comm is not None:
             _check(self.lib.mg_create_distributed_hostcomm(C.byref(desc), device, rank, nranks, C.byref(host_comm), C.byref(self.h)))
         elif nranks > 1:
             buf = C.create_string_buffer(comm_id, MG_COMM_ID_BYTES)

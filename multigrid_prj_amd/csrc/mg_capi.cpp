@@ -310,4 +310,19 @@ int mg_create_distributed_hostcomm(const mg_desc *desc, int device, int rank, in
     });
 }
 
+int mg_create_distributed_dryrun(const mg_desc *desc, int device, int rank, int nranks, mg_handle *out)
+{
+    return guarded([&]() -> int {
+        if (!out) return bad("mg_create_distributed_dryrun: null output handle");
+        *out = nullptr;
+        std::string why;
+        int rc = mg::validate_desc(desc, &why);
+        if (rc) { mg::set_last_error("mg_create_distributed_dryrun: " + why); return rc; }
+        mg::SlabPlan p;
+        rc = mg::plan_slab(*desc, nranks, rank, 0, &p, &why);
+        if (rc) { mg::set_last_error("mg_create_distributed_dryrun: " + why); return rc; }
+        return create_with_comm(desc, device, rank, nranks, mg::make_dry_comm(rank, nranks), out);
+    });
+}
+
 }  // extern "C"

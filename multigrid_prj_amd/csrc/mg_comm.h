@@ -36,6 +36,7 @@ public:
 // returns nullptr and sets *why on failure
 Comm *make_rccl_comm(int rank, int nranks, const void *id128, std::string *why);
 Comm *make_host_comm(int rank, int nranks, const mg_host_comm &cb, std::string *why);
+Comm *make_dry_comm(int rank, int nranks);  // moves nothing: timing of one rank's schedule only
 int rccl_unique_id(void *id128, std::string *why);
 
 }  // namespace mg

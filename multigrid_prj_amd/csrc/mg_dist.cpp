@@ -129,6 +129,26 @@ public:
 };
 }  // namespace
 
+// Dry run: rank `rank` of `nranks` with nobody on the other side. Nothing moves (ghost planes keep whatever they hold,
+// sums stay local), so the numbers a handle on it produces mean nothing; what it gives is ONE rank's launch schedule --
+// slab kernels, boundary launches, the replicated coarse levels -- timed on a single GPU (bench.py --transport dry).
+namespace {
+class DryComm : public Comm {
+public:
+    const char *name() const override { return "dry-run"; }
+    int transport_ranks() const override { return 1; }
+    int batch(const P2POp *, int, hipStream_t) override { return MG_OK; }
+    int allreduce_sum(double *, int, hipStream_t) override { return MG_OK; }
+};
+}  // namespace
+
+Comm *make_dry_comm(int rank, int nranks)
+{
+    DryComm *c = new DryComm();
+    c->rank = rank; c->nranks = nranks;
+    return c;
+}
+
 Comm *make_host_comm(int rank, int nranks, const mg_host_comm &cb, std::string *why)
 {
     if (!cb.batch || !cb.allreduce_sum) { if (why) *why = "host comm callbacks missing"; return nullptr; }

@@ -23,6 +23,7 @@
 #include "mg_kernels.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace mg {
@@ -243,12 +244,32 @@ constexpr int J2_TYO = 2;
 // short ones give the smaller levels enough workgroups to fill 256 CUs x 3. Measured per V-cycle:
 // 513^3: 24 planes (16: +1.2 %, 32: +2 %, 8: +5 %); 257^3: 8 (16: +6 %, 4: +3 %); 129^3: 4 (8: +3 %);
 // the rule below gives 24 / 8 / 3 there.
-static int j2_nbz(const Geom &g)
+static int j2_nbz(const Geom &g, int tpr)
 {
     static const int zc_env = [] { const char *e = getenv("MG_J2_ZC"); return e ? atoi(e) : 0; }();
+    static const bool slab_rule = [] { const char *e = getenv("MG_J2_SLAB_RULE"); return !(e && e[0] == '0'); }();
     int zc = 3;  // the longest march that still leaves enough workgroups (semi-coarsened levels: long in z, few rows)
     if (zc_env > 1) zc = zc_env;
-    else {
+    else if (slab_rule && g.gnz != g.nz && g.nz >= 8) {
+        // A piece of a z-slab (the interior planes of a rank's share of a distributed level): a few dozen to a few hundred planes,
+        // where the rule below would cut 60 planes into 20 marches of 3 (5 first-sweep planes per 3 outputs). Measured on one
+        // rank's schedule (tools/dry_zc.sh, 513^2 planes): the best chunk count is the one whose workgroups fill a whole
+        // number of rounds of the chip's resident workgroups from just below -- 60 planes: 4 marches of 15 (142 us per pair
+        // against 167), 124 planes: 4 of 31 (234 against 267), 253 planes: 13 of 20 (440 against 451).
+        const int nby = (g.ny + 2) / 3;
+        const int slots = 256 * (tpr >= 512 ? 1 : 12 / (tpr / 64));   // resident workgroups: 12 waves per CU at 167 VGPRs
+        int bestk = 1; double best = 1e30;
+        for (int k = 1; k <= g.nz / 4; k++) {
+            const int z = (g.nz + k - 1) / k;
+            if (z > 32 && k < g.nz / 4) continue;
+            const double r = (double)nby * k / slots;
+            // a round that overflows by ONE workgroup costs a whole march (9 marches of 29 at 253 planes = 1539 workgroups on
+            // 1536 slots: 431 us against 395): anything within 3 % of the next round counts as that round
+            const double cost = ceil(r + 0.03) * (z + 4);
+            if (cost < best - 1e-9 || (cost < best + 1e-9 && z < (g.nz + bestk - 1) / bestk)) { best = cost; bestk = k; }
+        }
+        return bestk;
+    } else {
         const int nby = (g.ny + 2) / 3;
         for (int cand : {24, 16, 12, 8, 6, 4})
             if (nby * ((g.nz + cand - 1) / cand) >= 2800) { zc = cand; break; }
@@ -269,9 +290,9 @@ static int j2_nbz(const Geom &g)
 // MINW: minimum waves per SIMD the register allocation is held to (3 = 168 VGPRs; 2 = 256: the fp32 folding variant spills otherwise)
 template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false, bool ZEROU = false, int TYO_ = J2_TYO,
           int MINW = 3>
-__global__ __launch_bounds__(TPR, MINW) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u,
-                                                 const T *__restrict__ rhs, T *__restrict__ out, int nby, int nbz,
-                                                 const T *__restrict__ coarse, Geom gc)
+__global__ __launch_bounds__(TPR, MINW) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u_,
+                                                 const T *__restrict__ rhs_, T *__restrict__ out_, int nby, int nbz,
+                                                 const T *__restrict__ coarse, Geom gc, int dup_planes)
 {
     constexpr int V = VecOf<T>::V, TYO = TYO_, TYV = TYO + 2;
     constexpr int CV = V / 2;  // coarse columns owned by this thread
@@ -286,10 +307,19 @@ __global__ __launch_bounds__(TPR, MINW) void k_jacobi2(Geom g, Coef<T> c, T omeg
     constexpr int NWV = TPR / 64;
     __shared__ T uedge[2][TYV][NWV][2];
     __shared__ T utail[2][TYV];  // u(nx-1): the right neighbour of the row's last vector
-    const int nblocks = nby * nbz;
-    const int per = (nblocks + 7) >> 3;
-    const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order
-    if (bid >= nblocks) return;                                   // whole workgroup
+    // dup_planes > 0: ONE launch runs the same geometry twice, the second copy dup_planes planes further up (the two
+    // boundary pieces of a z-slab, mg_solver.cpp: pair_on_slab2_t): the workgroups of the second half shift their
+    // pointers and the global plane index of local plane 0 -- everything below is unchanged (all of it scalar)
+    const int nblocks = nby * nbz, ntotal = dup_planes > 0 ? 2 * nblocks : nblocks;
+    const int per = (ntotal + 7) >> 3;
+    int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);         // XCD-aware order
+    if (bid >= ntotal) return;                                    // whole workgroup
+    const bool second = bid >= nblocks;
+    if (second) { bid -= nblocks; g.gz0 += dup_planes; }
+    const long long dup_off = second ? (long long)dup_planes * g.plane : 0;
+    const T *__restrict__ u = u_ + dup_off;
+    const T *__restrict__ rhs = rhs_ + dup_off;
+    T *__restrict__ out = out_ + dup_off;
     const int by = bid % nby, bz = bid / nby;
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);    // wave index: scalar
@@ -727,23 +757,24 @@ bool jacobi2_slab_ok(const Geom &g)
 }
 
 template <typename T>
-void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out, bool zero_u)
+void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out, bool zero_u, int dup)
 {
     constexpr int V = VecOf<T>::V;
     const int tpr = (g.nx - 1) / V;
-    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
-    const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
+    const int ncopy = dup > 0 ? 2 : 1;   // dup: the same geometry once more, `dup` planes further up, in the same launch
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g, tpr);
+    const int nblocks = nby * nbz, grid = ((ncopy * nblocks + 7) / 8) * 8;
     const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
     // three output rows per workgroup where the correction is not folded in: 5 instead of 4 first-sweep rows
     // per 3 instead of 2 outputs, 167 VGPRs (still 3 workgroups/CU): 0.86 -> 0.79 ms per pair at 513^3
     static const int tyo_env = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
     const int tyo = j2_tyo_for(tpr, tyo_env);
-    const int nby3 = (g.ny + 2) / 3, grid3 = ((nby3 * nbz + 7) / 8) * 8;
+    const int nby3 = (g.ny + 2) / 3, grid3 = ((ncopy * nby3 * nbz + 7) / 8) * 8;
 #define MG_J2K(TPR, D, N, Z) \
     do { \
         constexpr int TY3 = (TPR > 384) ? 2 : 3; /* never launched with three rows at 512 threads: no such instantiation */ \
-        if (tyo == 3) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z, TY3>), dim3(grid3), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}); \
-        else hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
+        if (tyo == 3) hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z, TY3>), dim3(grid3), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}, dup); \
+        else hipLaunchKernelGGL((k_jacobi2<T, TPR, D, N, false, false, Z>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}, dup); \
     } while (0)
 #define MG_J2(TPR) \
     do { \
@@ -774,20 +805,22 @@ bool rb_fused_ok(const Geom &g)
 // coarse != nullptr: the sweep reads u + P coarse (prolong-add folded in, like launch_jacobi2_corr)
 template <typename T>
 void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs, T *out,
-                     const T *coarse, const Geom &gc)
+                     const T *coarse, const Geom &gc, int dup)
 {
     constexpr int V = VecOf<T>::V;
     const int tpr = (g.nx - 1) / V;
-    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
-    const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
+    const int ncopy = (dup > 0 && !coarse) ? 2 : 1;
+    if (coarse) dup = 0;   // the folding variant only runs on whole levels
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g, tpr);
+    const int nblocks = nby * nbz, grid = ((ncopy * nblocks + 7) / 8) * 8;
     static const int tyo_env = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
     const int tyo = j2_tyo_for(tpr, tyo_env);
-    const int nby3 = (g.ny + 2) / 3, grid3 = ((nby3 * nbz + 7) / 8) * 8;
+    const int nby3 = (g.ny + 2) / 3, grid3 = ((ncopy * nby3 * nbz + 7) / 8) * 8;
 #define MG_RB2(TPR) \
     do { \
-        if (coarse) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, coarse, gc); \
-        else if (tyo == 3) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true, false, (TPR > 384) ? 2 : 3>), dim3(grid3), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}); \
-        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}); \
+        if (coarse) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, coarse, gc, 0); \
+        else if (tyo == 3) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true, false, (TPR > 384) ? 2 : 3>), dim3(grid3), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}, dup); \
+        else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}, dup); \
     } while (0)
     switch (tpr) {
     case 512: MG_RB2(512); break;
@@ -802,8 +835,8 @@ void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
 
 template bool rb_fused_ok<double>(const Geom &);
 template bool rb_fused_ok<float>(const Geom &);
-template void launch_rb_fused<double>(hipStream_t, const Geom &, const Coef<double> &, const double *, const double *, double *, const double *, const Geom &);
-template void launch_rb_fused<float>(hipStream_t, const Geom &, const Coef<float> &, const float *, const float *, float *, const float *, const Geom &);
+template void launch_rb_fused<double>(hipStream_t, const Geom &, const Coef<double> &, const double *, const double *, double *, const double *, const Geom &, int);
+template void launch_rb_fused<float>(hipStream_t, const Geom &, const Coef<float> &, const float *, const float *, float *, const float *, const Geom &, int);
 
 // prolong-add + two Jacobi sweeps in one pass: out = J(J(u + P coarse))
 template <typename T>
@@ -819,7 +852,7 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
 {
     constexpr int V = VecOf<T>::V;
     const int tpr = (g.nx - 1) / V;
-    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g);
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g, tpr);
     const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
     const bool damped = (omega != (T)1);
     static const int minw_env = [] { const char *e = getenv("MG_J2C_MINW"); return e ? atoi(e) : 0; }();
@@ -829,11 +862,11 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
 #define MG_J2C(TPR) \
     do { \
         if (minw == 2) { \
-            if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true, false, false, 2, 2>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
-            else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, false, false, 2, 2>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
+            if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true, false, false, 2, 2>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 0); \
+            else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, false, false, 2, 2>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 0); \
         } else { \
-            if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
-            else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc); \
+            if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 0); \
+            else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 0); \
         } \
     } while (0)
     switch (tpr) {
@@ -853,10 +886,10 @@ template void launch_jacobi2_corr<double>(hipStream_t, const Geom &, const Geom 
 template void launch_jacobi2_corr<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, float, const float *, const float *, const float *, float *);
 template bool jacobi2_ok<double>(const Geom &);
 template bool jacobi2_ok<float>(const Geom &);
-template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *, bool);
+template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *, bool, int);
 template bool jacobi2_slab_ok<double>(const Geom &);
 template bool jacobi2_slab_ok<float>(const Geom &);
-template void launch_jacobi2<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *, bool);
+template void launch_jacobi2<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *, bool, int);
 template bool fast_path_ok<double>(const Geom &);
 template bool fast_path_ok<float>(const Geom &);
 template int fast_partials_capacity<double>(const Geom &);

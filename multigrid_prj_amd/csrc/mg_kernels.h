@@ -28,7 +28,7 @@ void launch_jacobi_fast(hipStream_t s, const Geom &g, const Coef<T> &c, T omega,
 template <typename T> bool jacobi2_ok(const Geom &g);
 template <typename T>
 void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out,
-                    bool zero_u = false);
+                    bool zero_u = false, int dup_planes = 0);  // dup_planes > 0: the same geometry once more, that many planes further up, in the same launch
 // z-slab of a distributed level: the pair on its inner planes (launch_jacobi2 with g = planes 1 .. nz-2), see pair_on_slab_t
 template <typename T> bool jacobi2_slab_ok(const Geom &slab);
 // the same with the V-cycle's prolong-add folded in: out = J(J(u + P coarse)); u is not modified
@@ -50,7 +50,7 @@ template <typename T> void zebra_line_factors(T cl, T cd, int n, T *out);
 template <typename T> bool rb_fused_ok(const Geom &g);
 template <typename T>
 void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs, T *out,
-                     const T *coarse, const Geom &gc);
+                     const T *coarse, const Geom &gc, int dup_planes = 0);
 // out-of-place colour half-sweep (the other colour is copied): red u->tmp, black tmp->u
 template <typename T>
 void launch_rb_fast(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, const T *u, const T *rhs, T *out);
@@ -69,7 +69,9 @@ template <typename T> bool resid_restrict_fast_ok(const Geom &gf, const Geom &gc
 template <typename T> bool resid_restrict_slab_ok(const Geom &gf, const Geom &gc);
 template <typename T>
 void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, const Coef<T> &c, const T *u,
-                              const T *rhs, T *coarse);
+                              const T *rhs, T *coarse, int dup_kc = 0, int dup_nzf = 0);
+// dup_kc > 0 (gc.nz must be 1): a second single coarse plane dup_kc coarse planes further up (its fine planes start 2 dup_kc
+// further up and there are dup_nzf of them) in the same launch -- the two boundary pieces of a z-slab
 
 // one colour half-sweep of red-black Gauss-Seidel, in place
 template <typename T>

@@ -711,10 +711,12 @@ int Solver::pair_on_slab2_t(int level, bool rb)
     const T om = (T)d_.omega;
     T *px = ptr<T>(MG_ARR_U, level), *pr = ptr<T>(MG_ARR_RHS, level), *pt = ptr<T>(MG_ARR_TMP, level);
     const long long pl = g.plane;
-    auto fused = [&](const Geom &gs, long long off) {
-        if (rb) launch_rb_fused<T>(stream_, gs, c, px + off, pr + off, pt + off, (const T *)nullptr, gs);
-        else launch_jacobi2<T>(stream_, gs, c, om, px + off, pr + off, pt + off, false);
+    // dup > 0: the same piece once more, `dup` planes further up, in the same launch
+    auto fused = [&](const Geom &gs, long long off, int dup = 0) {
+        if (rb) launch_rb_fused<T>(stream_, gs, c, px + off, pr + off, pt + off, (const T *)nullptr, gs, dup);
+        else launch_jacobi2<T>(stream_, gs, c, om, px + off, pr + off, pt + off, false, dup);
     };
+    static const bool one_boundary_launch = [] { const char *e = getenv("MG_MERGE_BOUNDARY"); return !(e && e[0] == '0'); }();
     MG_TRY(refresh_rhs_halo(level));
     if (!overlap_ || g.nz < 8) {
         MG_TRY(exchange(MG_ARR_U, level, 2));
@@ -725,9 +727,13 @@ int Solver::pair_on_slab2_t(int level, bool rb)
         fused(gi, 2 * pl);
         MG_TRY(exchange_end());
         Geom glo = g; glo.nz = 2;
-        fused(glo, 0);
-        Geom ghi = g; ghi.nz = 2; ghi.gz0 = g.gz0 + g.nz - 2;
-        fused(ghi, (long long)(g.nz - 2) * pl);
+        if (one_boundary_launch) {           // output planes 0, 1 and nz-2, nz-1 in ONE launch (two were 2 x 15 us at 513^2)
+            fused(glo, 0, g.nz - 2);
+        } else {
+            fused(glo, 0);
+            Geom ghi = g; ghi.nz = 2; ghi.gz0 = g.gz0 + g.nz - 2;
+            fused(ghi, (long long)(g.nz - 2) * pl);
+        }
     }
     MG_HIP(hipGetLastError());
     std::swap(L.base[MG_ARR_U], L.base[MG_ARR_TMP]);
@@ -756,14 +762,19 @@ int Solver::resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs)
         Geom gfi = gf; gfi.nz = 2 * gci.nz; gfi.gz0 = gf.gz0 + 2;
         launch_resid_restrict_fw<T>(stream_, gfi, gci, c, pu + 2 * gf.plane, pr + 2 * gf.plane, coarse_rhs + gc.plane);
         MG_TRY(exchange_end());
+        static const bool one_boundary_launch = [] { const char *e = getenv("MG_MERGE_BOUNDARY"); return !(e && e[0] == '0'); }();
         Geom gc0 = gc; gc0.nz = 1;
         Geom gf0 = gf; gf0.nz = 2;
-        launch_resid_restrict_fw<T>(stream_, gf0, gc0, c, pu, pr, coarse_rhs);
         const int kl = gc.nz - 1;                 // last coarse plane: fine planes 2 kl (and 2 kl + 1 unless it is the grid's top plane)
-        Geom gc1 = gc; gc1.nz = 1; gc1.gz0 = gc.gz0 + kl;
-        Geom gf1 = gf; gf1.nz = gf.nz - 2 * kl; gf1.gz0 = gf.gz0 + 2 * kl;
-        launch_resid_restrict_fw<T>(stream_, gf1, gc1, c, pu + (long long)2 * kl * gf.plane, pr + (long long)2 * kl * gf.plane,
-                                    coarse_rhs + (long long)kl * gc.plane);
+        if (one_boundary_launch) {                // first and last coarse plane in ONE launch
+            launch_resid_restrict_fw<T>(stream_, gf0, gc0, c, pu, pr, coarse_rhs, kl, gf.nz - 2 * kl);
+        } else {
+            launch_resid_restrict_fw<T>(stream_, gf0, gc0, c, pu, pr, coarse_rhs);
+            Geom gc1 = gc; gc1.nz = 1; gc1.gz0 = gc.gz0 + kl;
+            Geom gf1 = gf; gf1.nz = gf.nz - 2 * kl; gf1.gz0 = gf.gz0 + 2 * kl;
+            launch_resid_restrict_fw<T>(stream_, gf1, gc1, c, pu + (long long)2 * kl * gf.plane, pr + (long long)2 * kl * gf.plane,
+                                        coarse_rhs + (long long)kl * gc.plane);
+        }
     }
     MG_HIP(hipGetLastError());
     return MG_OK;

@@ -167,9 +167,9 @@ __device__ __forceinline__ double prev_lane(double v, double edge)
 // workgroups recompute the shared odd row: 1.5x residual work for CR = 1, 1.25x for CR = 2).
 // SEMI: semi-coarsening transition: every fine plane is a coarse plane, 9-point weights per plane
 template <typename T, bool NTLOAD, int CR, bool SEMI>
-__global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coef<T> c, const T *__restrict__ u,
-                                                            const T *__restrict__ rhs, T *__restrict__ coarse,
-                                                            int nby, int nbz, int zcc)
+__global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coef<T> c, const T *__restrict__ u_,
+                                                            const T *__restrict__ rhs_, T *__restrict__ coarse_,
+                                                            int nby, int nbz, int zcc, int dup_kc, int dup_nzf)
 {
     constexpr int V = PV<T>::V, CV = V / 2, NR = 2 * CR + 1;
     typedef typename PV<T>::vec vec;
@@ -179,10 +179,18 @@ __global__ __launch_bounds__(512) void k_resid_restrict_fw(Geom gf, Geom gc, Coe
     // lane needs a value no wave holds (the column after the last vector), fetched one plane ahead
     __shared__ T ued[2][NR][8][2];
     __shared__ T utl[2][NR];
-    const int nblocks = nby * nbz;
-    const int per = (nblocks + 7) >> 3;
-    const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order
-    if (bid >= nblocks) return;                                   // whole workgroup
+    // dup_kc > 0: the launch covers a second single coarse plane, dup_kc coarse planes (2 dup_kc fine planes) further up,
+    // with dup_nzf fine planes: the second half of the workgroups shift pointers and plane indices (all scalar)
+    const int nblocks = nby * nbz, ntotal = dup_kc > 0 ? 2 * nblocks : nblocks;
+    const int per = (ntotal + 7) >> 3;
+    int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware order
+    if (bid >= ntotal) return;                                    // whole workgroup
+    const bool second = bid >= nblocks;
+    if (second) { bid -= nblocks; gf.gz0 += 2 * dup_kc; gf.nz = dup_nzf; gc.gz0 += dup_kc; }
+    const long long foff = second ? (long long)2 * dup_kc * gf.plane : 0;
+    const T *__restrict__ u = u_ + foff;
+    const T *__restrict__ rhs = rhs_ + foff;
+    T *__restrict__ coarse = coarse_ + (second ? (long long)dup_kc * gc.plane : 0);
     const int J0 = (bid % nby) * CR, bz = bid / nby;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (int)(blockDim.x >> 6);
     const int wl = max(wv - 1, 0), wr = min(wv + 1, nwv - 1);
@@ -421,7 +429,7 @@ bool resid_restrict_slab_ok(const Geom &gf, const Geom &gc)
 
 template <typename T>
 void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, const Coef<T> &c, const T *u,
-                              const T *rhs, T *coarse)
+                              const T *rhs, T *coarse, int dup_kc, int dup_nzf)
 {
     constexpr int CV = PV<T>::V / 2;
     constexpr int CR = 1;                                     // coarse rows per workgroup (2 measured slower again after the mailbox change: 185 VGPRs, 3.28 vs 3.10 ms per cycle)
@@ -434,14 +442,15 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
     // the chip: one coarse plane per workgroup there
     if (zcc_env <= 0 && nby * ((gc.nz + zcc - 1) / zcc) < 1024) zcc = 1;
     const int nbz = (gc.nz + zcc - 1) / zcc;
-    const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
+    if (gc.nz != 1) dup_kc = 0;
+    const int nblocks = nby * nbz, grid = (((dup_kc > 0 ? 2 : 1) * nblocks + 7) / 8) * 8;
     const bool nt = (size_t)gf.nz * gf.plane * sizeof(T) >= ((size_t)64 << 20);
     if (transfer_is_semi(gf, gc)) {
-        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc);
-        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc);
+        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc, dup_kc, dup_nzf);
+        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc, dup_kc, dup_nzf);
     } else {
-        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc);
-        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc);
+        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc, dup_kc, dup_nzf);
+        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc, dup_kc, dup_nzf);
     }
 }
 
@@ -449,7 +458,7 @@ template bool resid_restrict_slab_ok<double>(const Geom &, const Geom &);
 template bool resid_restrict_slab_ok<float>(const Geom &, const Geom &);
 template bool resid_restrict_fast_ok<double>(const Geom &, const Geom &);
 template bool resid_restrict_fast_ok<float>(const Geom &, const Geom &);
-template void launch_resid_restrict_fw<double>(hipStream_t, const Geom &, const Geom &, const Coef<double> &, const double *, const double *, double *);
-template void launch_resid_restrict_fw<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, const float *, const float *, float *);
+template void launch_resid_restrict_fw<double>(hipStream_t, const Geom &, const Geom &, const Coef<double> &, const double *, const double *, double *, int, int);
+template void launch_resid_restrict_fw<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, const float *, const float *, float *, int, int);
 
 }  // namespace mg
