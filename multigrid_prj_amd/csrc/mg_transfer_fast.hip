@@ -437,7 +437,13 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
     const int nw = (ncol + 64 * CV - 1) / (64 * CV);          // waves side by side in x (<= 8)
     const int nby = (gc.ny + CR - 1) / CR;
     static const int zcc_env = [] { const char *e = getenv("MG_RR_ZCC"); return e ? atoi(e) : 0; }();
-    int zcc = zcc_env > 0 ? zcc_env : 4;                     // coarse planes marched per workgroup
+    static const int zcc_big = [] { const char *e = getenv("MG_RR_ZCC_BIG"); return e ? atoi(e) : 0; }();
+    // Coarse planes marched per workgroup: 4; 7 on a level whose arrays stream from HBM (>= 512 MB: 513^3 fp64 and up). Measured
+    // at 513^3 over 4 ... 43 on two boxes (tools/sweep_env.sh MG_RR_ZCC_BIG): 6, 7, 10, 11, 14 take 0.52-0.55 ms where 4, 8, 9, 12,
+    // 13, 16 take 0.56-0.61 (11 -> 9 u planes read per 8 owned; the in-between values lose it again to how their chunk stride
+    // falls on the memory channels); 7 was the best value that was good on both. Slabs and smaller levels: no difference (tools/dry_sweep.sh).
+    int zcc = zcc_env > 0 ? zcc_env : 4;
+    if (zcc_env <= 0 && (size_t)gf.nz * gf.plane * sizeof(T) >= ((size_t)512 << 20)) zcc = zcc_big > 0 ? zcc_big : 7;
     // small levels are latency-bound (one dependent memory round trip per marched plane) and their grids do not fill
     // the chip: one coarse plane per workgroup there
     if (zcc_env <= 0 && nby * ((gc.nz + zcc - 1) / zcc) < 1024) zcc = 1;
@@ -445,13 +451,12 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
     if (gc.nz != 1) dup_kc = 0;
     const int nblocks = nby * nbz, grid = (((dup_kc > 0 ? 2 : 1) * nblocks + 7) / 8) * 8;
     const bool nt = (size_t)gf.nz * gf.plane * sizeof(T) >= ((size_t)64 << 20);
-    if (transfer_is_semi(gf, gc)) {
-        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc, dup_kc, dup_nzf);
-        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, true>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc, dup_kc, dup_nzf);
-    } else {
-        if (nt) hipLaunchKernelGGL((k_resid_restrict_fw<T, true, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc, dup_kc, dup_nzf);
-        else hipLaunchKernelGGL((k_resid_restrict_fw<T, false, CR, false>), dim3(grid), dim3(64 * nw), 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc, dup_kc, dup_nzf);
-    }
+    const dim3 bl(64 * nw);
+#define MG_RR(NT, SEMI) \
+    hipLaunchKernelGGL((k_resid_restrict_fw<T, NT, CR, SEMI>), dim3(grid), bl, 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc, dup_kc, dup_nzf)
+    if (transfer_is_semi(gf, gc)) { if (nt) MG_RR(true, true); else MG_RR(false, true); }
+    else { if (nt) MG_RR(true, false); else MG_RR(false, false); }
+#undef MG_RR
 }
 
 template bool resid_restrict_slab_ok<double>(const Geom &, const Geom &);

@@ -40,3 +40,18 @@ def test_bench_launcher_deadline():
     """A rank that never finishes (here: rank 1 waits for a rendezvous rank 0 never joins) ends the run."""
     p = _run(["--gpus", "2", "--rehearse", "--grid", "65", "--levels", "3", "--rehearse-fail-rank", "0", "--launch-timeout", "20"])
     assert p.returncode != 0
+
+
+@pytest.mark.gpu
+def test_bench_dry_rank_runs_one_ranks_schedule_on_one_gpu():
+    """--dry-rank R: one process plays rank R of N with no peers (measurement tool). The line must say so, and a middle
+    rank's schedule must post the same message groups per cycle as the real transports do (nothing moves)."""
+    p = _run(["--gpus", "4", "--dry-rank", "1", "--steps", "3", "--warmup", "1", "--grid", "129", "--levels", "4", "--dist-min-n", "65",
+              "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert "dry_run" in out and "WITHOUT communication" in out["dry_run"]
+    assert out["transport"] == "dry-run" and out["rccl_ranks"] is None and out["n_gpus"] == 4
+    assert out["comm_per_cycle"]["message_groups"] > 0 and out["ms_per_step"] > 0
