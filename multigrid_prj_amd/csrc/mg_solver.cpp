@@ -437,7 +437,7 @@ int Solver::exchange(int which, int level, int depth)
     return rc;
 }
 
-int Solver::exchange_begin(int which, int level, int depth)
+int Solver::exchange_begin(int which, int level, int depth, bool record)
 {
     Level &L = lv_[level];
     if (depth > L.gh || depth > L.nz_min) { set_last_error("halo exchange deeper than the ghost planes / the thinnest slab"); return MG_ERR_BAD_ARG; }
@@ -447,8 +447,23 @@ int Solver::exchange_begin(int which, int level, int depth)
     MG_HIP(hipStreamWaitEvent(comm_stream_, ev_ready_, 0));
     int rc = post(ops, n, comm_stream_);
     if (rc) { set_last_error("halo exchange failed"); return rc; }
+    if (record) MG_HIP(hipEventRecord(ev_halo_, comm_stream_));
+    return MG_OK;
+}
+
+int Solver::halo_work_done()
+{
     MG_HIP(hipEventRecord(ev_halo_, comm_stream_));
     return MG_OK;
+}
+
+// The boundary pieces of a slab operation (the planes that need the halo) run on the COMMUNICATION stream, right behind
+// the exchange, while the interior piece runs on the main stream: measured on one rank's schedule (tools/dry_ranks.sh) the
+// boundary launch after the interior one cost 14-18 us plus a cross-stream wait per operation, five operations per cycle.
+static bool boundary_on_comm_stream()
+{
+    static const bool e = [] { const char *v = getenv("MG_BOUNDARY_ON_COMM"); return !(v && v[0] == '0'); }();
+    return e;
 }
 
 int Solver::exchange_end()
@@ -712,9 +727,10 @@ int Solver::pair_on_slab2_t(int level, bool rb)
     T *px = ptr<T>(MG_ARR_U, level), *pr = ptr<T>(MG_ARR_RHS, level), *pt = ptr<T>(MG_ARR_TMP, level);
     const long long pl = g.plane;
     // dup > 0: the same piece once more, `dup` planes further up, in the same launch
-    auto fused = [&](const Geom &gs, long long off, int dup = 0) {
-        if (rb) launch_rb_fused<T>(stream_, gs, c, px + off, pr + off, pt + off, (const T *)nullptr, gs, dup);
-        else launch_jacobi2<T>(stream_, gs, c, om, px + off, pr + off, pt + off, false, dup);
+    auto fused = [&](const Geom &gs, long long off, int dup = 0, hipStream_t st = nullptr) {
+        if (!st) st = stream_;
+        if (rb) launch_rb_fused<T>(st, gs, c, px + off, pr + off, pt + off, (const T *)nullptr, gs, dup);
+        else launch_jacobi2<T>(st, gs, c, om, px + off, pr + off, pt + off, false, dup);
     };
     static const bool one_boundary_launch = [] { const char *e = getenv("MG_MERGE_BOUNDARY"); return !(e && e[0] == '0'); }();
     MG_TRY(refresh_rhs_halo(level));
@@ -722,12 +738,18 @@ int Solver::pair_on_slab2_t(int level, bool rb)
         MG_TRY(exchange(MG_ARR_U, level, 2));
         fused(g, 0);
     } else {
-        MG_TRY(exchange_begin(MG_ARR_U, level, 2));
+        const bool on_comm = one_boundary_launch && boundary_on_comm_stream();
+        MG_TRY(exchange_begin(MG_ARR_U, level, 2, !on_comm));
         Geom gi = g; gi.nz = g.nz - 4; gi.gz0 = g.gz0 + 2;     // reads u on planes 0 .. nz-1 only
+        Geom glo = g; glo.nz = 2;
+        if (on_comm) {                       // the boundary planes follow the halo on its own stream, beside the interior launch
+            fused(glo, 0, g.nz - 2, comm_stream_);
+            MG_TRY(halo_work_done());
+        }
         fused(gi, 2 * pl);
         MG_TRY(exchange_end());
-        Geom glo = g; glo.nz = 2;
-        if (one_boundary_launch) {           // output planes 0, 1 and nz-2, nz-1 in ONE launch (two were 2 x 15 us at 513^2)
+        if (on_comm) {
+        } else if (one_boundary_launch) {    // output planes 0, 1 and nz-2, nz-1 in ONE launch (two were 2 x 15 us at 513^2)
             fused(glo, 0, g.nz - 2);
         } else {
             fused(glo, 0);
@@ -757,16 +779,22 @@ int Solver::resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs)
         launch_resid_restrict_fw<T>(stream_, gf, gc, c, pu, pr, coarse_rhs);
     } else {
         // coarse planes 1 .. nzc-2 read u on owned planes only: they run while the halo moves
-        MG_TRY(exchange_begin(MG_ARR_U, level, 2));
+        static const bool one_boundary_launch = [] { const char *e = getenv("MG_MERGE_BOUNDARY"); return !(e && e[0] == '0'); }();
+        const bool on_comm = one_boundary_launch && boundary_on_comm_stream();
+        MG_TRY(exchange_begin(MG_ARR_U, level, 2, !on_comm));
+        Geom gc0 = gc; gc0.nz = 1;
+        Geom gf0 = gf; gf0.nz = 2;
+        const int kl = gc.nz - 1;                 // last coarse plane: fine planes 2 kl (and 2 kl + 1 unless it is the grid's top plane)
+        if (on_comm) {                            // first and last coarse plane behind the halo on its own stream
+            launch_resid_restrict_fw<T>(comm_stream_, gf0, gc0, c, pu, pr, coarse_rhs, kl, gf.nz - 2 * kl);
+            MG_TRY(halo_work_done());
+        }
         Geom gci = gc; gci.nz = gc.nz - 2; gci.gz0 = gc.gz0 + 1;
         Geom gfi = gf; gfi.nz = 2 * gci.nz; gfi.gz0 = gf.gz0 + 2;
         launch_resid_restrict_fw<T>(stream_, gfi, gci, c, pu + 2 * gf.plane, pr + 2 * gf.plane, coarse_rhs + gc.plane);
         MG_TRY(exchange_end());
-        static const bool one_boundary_launch = [] { const char *e = getenv("MG_MERGE_BOUNDARY"); return !(e && e[0] == '0'); }();
-        Geom gc0 = gc; gc0.nz = 1;
-        Geom gf0 = gf; gf0.nz = 2;
-        const int kl = gc.nz - 1;                 // last coarse plane: fine planes 2 kl (and 2 kl + 1 unless it is the grid's top plane)
-        if (one_boundary_launch) {                // first and last coarse plane in ONE launch
+        if (on_comm) {
+        } else if (one_boundary_launch) {         // first and last coarse plane in ONE launch
             launch_resid_restrict_fw<T>(stream_, gf0, gc0, c, pu, pr, coarse_rhs, kl, gf.nz - 2 * kl);
         } else {
             launch_resid_restrict_fw<T>(stream_, gf0, gc0, c, pu, pr, coarse_rhs);

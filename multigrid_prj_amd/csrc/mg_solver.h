@@ -114,7 +114,10 @@ private:
     // for one workgroup and the mode is MG_COARSE_FIXED -- coarse_maxit regular sweeps
     template <typename T> int coarse_level_t(int l, int ax, int ar);  // coarse solve of a still-distributed coarsest level, gathered
     int exchange(int which, int level, int depth = 1);        // `depth` ghost planes <-> z-neighbours (on the main stream)
-    int exchange_begin(int which, int level, int depth = 1);  // the same on the comm stream, after the main stream's work so far
+    // the same on the comm stream, after the main stream's work so far; record = false: the caller puts more work that needs the halo
+    // on the comm stream (the boundary pieces of a slab operation) and records the event itself with halo_work_done()
+    int exchange_begin(int which, int level, int depth = 1, bool record = true);
+    int halo_work_done();
     int halo_ops(int which, int level, int depth, P2POp *ops);
     int exchange_end();                          // main stream waits for the halo
     // Runs a stencil launch over a distributed level with the halo exchange of `arr_x` hidden
