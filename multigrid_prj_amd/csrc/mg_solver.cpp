@@ -197,7 +197,14 @@ int Solver::init()
     MG_HIP(hipEventCreate(&ev0_));
     MG_HIP(hipEventCreate(&ev1_));
     if (nranks_ > 1) {
-        MG_HIP(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+        // the communication stream outranks the main one: the exchange kernels and the boundary pieces behind them are
+        // dispatched ahead of the interior launch they run beside (MG_COMM_PRIORITY=0: same priority)
+        int prio_least = 0, prio_greatest = 0;
+        const char *pe = getenv("MG_COMM_PRIORITY");
+        if (!(pe && pe[0] == '0') && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_greatest != prio_least)
+            MG_HIP(hipStreamCreateWithPriority(&comm_stream_, hipStreamNonBlocking, prio_greatest));
+        else
+            MG_HIP(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
         MG_HIP(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
         MG_HIP(hipEventCreateWithFlags(&ev_halo_, hipEventDisableTiming));
         const char *ov = getenv("MG_OVERLAP");
