@@ -244,7 +244,7 @@ constexpr int J2_TYO = 2;
 // short ones give the smaller levels enough workgroups to fill 256 CUs x 3. Measured per V-cycle:
 // 513^3: 24 planes (16: +1.2 %, 32: +2 %, 8: +5 %); 257^3: 8 (16: +6 %, 4: +3 %); 129^3: 4 (8: +3 %);
 // the rule below gives 24 / 8 / 3 there.
-static int j2_nbz(const Geom &g, int tpr)
+static int j2_nbz(const Geom &g, int tpr, int tyo = 3)   // tyo: output rows per workgroup of the launch (slab rule only)
 {
     static const int zc_env = [] { const char *e = getenv("MG_J2_ZC"); return e ? atoi(e) : 0; }();
     static const bool slab_rule = [] { const char *e = getenv("MG_J2_SLAB_RULE"); return !(e && e[0] == '0'); }();
@@ -256,7 +256,7 @@ static int j2_nbz(const Geom &g, int tpr)
         // rank's schedule (tools/dry_zc.sh, 513^2 planes): the best chunk count is the one whose workgroups fill a whole
         // number of rounds of the chip's resident workgroups from just below -- 60 planes: 4 marches of 15 (142 us per pair
         // against 167), 124 planes: 4 of 31 (234 against 267), 253 planes: 13 of 20 (440 against 451).
-        const int nby = (g.ny + 2) / 3;
+        const int nby = (g.ny + tyo - 1) / tyo;
         const int slots = 256 * (tpr >= 512 ? 1 : 12 / (tpr / 64));   // resident workgroups: 12 waves per CU at 167 VGPRs
         int bestk = 1; double best = 1e30;
         for (int k = 1; k <= g.nz / 4; k++) {
@@ -345,9 +345,9 @@ __global__ __launch_bounds__(TPR, MINW) void k_jacobi2(Geom g, Coef<T> c, T omeg
     // zhalo = planes that exist below local plane 0 / above plane nz-1: 1 for a whole level (the ghost
     // planes), 2 when g describes the inner planes 1 .. nz-2 of a z-slab (pair_on_slab_t: the only
     // launches whose g is not the whole grid in z)
-    const int zhalo = (!CORR && g.gnz != g.nz) ? 2 : 1;
-    // global z of local plane 0 and global plane count (the folding variant only runs on whole levels)
-    const int gzo = CORR ? 0 : g.gz0, gzn = CORR ? g.nz : g.gnz;
+    const int zhalo = (g.gnz != g.nz) ? 2 : 1;
+    // global z of local plane 0 and global plane count
+    const int gzo = g.gz0, gzn = g.gnz;
     auto plane_of = [&](int p) { return (long long)min(max(p, -zhalo), g.nz - 1 + zhalo) * g.plane; };
 
     // ---- on-the-fly prolongation (CORR) ------------------------------------------------------
@@ -372,14 +372,20 @@ __global__ __launch_bounds__(TPR, MINW) void k_jacobi2(Geom g, Coef<T> c, T omeg
     };
     // Loads and arithmetic are kept apart so that a plane step issues ALL its loads (u, rhs,
     // coarse) before the first wait: raw_a/raw_b only load, zfin only computes.
-    auto cplane = [&](int P, int up1) { return coarse + (long long)((min(max(P, 0), g.nz - 1) + up1) >> 1) * gc.plane; };
+    // coarse plane under fine plane P (+1: the upper one of an odd plane), by GLOBAL plane index: `coarse` is local plane 0 of
+    // the coarse slab (gc.gz0 = its global index; a piece of a fine slab keeps the whole coarse slab's pointer). Planes outside the
+    // arrays' ghost planes are clamped (their values are not used: `in` below)
+    auto cplane = [&](int P, int up1) {
+        const int kc = ((gzo + P + up1) >> 1) - gc.gz0;
+        return coarse + (long long)min(max(kc, -zhalo), gc.nz - 1 + zhalo) * gc.plane;
+    };
     auto raw_a = [&](int P, T (&R)[4][NR]) {
         const T *c0 = cplane(P, 0);
 #pragma unroll
         for (int j = 0; j < 4; j++) load_crow(c0, j, R[j]);
     };
     auto raw_b = [&](int P, T (&R)[4][NR]) {  // the upper coarse plane of an odd fine plane
-        if (P & 1) {
+        if ((gzo + P) & 1) {
             const T *c1 = cplane(P, 1);
 #pragma unroll
             for (int j = 0; j < 4; j++) load_crow(c1, j, R[j]);
@@ -392,7 +398,8 @@ __global__ __launch_bounds__(TPR, MINW) void k_jacobi2(Geom g, Coef<T> c, T omeg
     };
     // Z[j][.]: coarse correction interpolated in z onto fine plane P (zero outside the grid)
     auto zfin = [&](int P, const T (&Ra)[4][NR], const T (&Rb)[4][NR], T (&Z)[4][NR]) {
-        const bool in = (P >= 0) && (P < g.nz), odd = (P & 1) != 0;
+        const int gP = gzo + P;
+        const bool in = (gP >= 0) && (gP < gzn), odd = (gP & 1) != 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
 #pragma unroll
@@ -762,13 +769,13 @@ void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, con
     constexpr int V = VecOf<T>::V;
     const int tpr = (g.nx - 1) / V;
     const int ncopy = dup > 0 ? 2 : 1;   // dup: the same geometry once more, `dup` planes further up, in the same launch
-    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g, tpr);
-    const int nblocks = nby * nbz, grid = ((ncopy * nblocks + 7) / 8) * 8;
-    const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
     // three output rows per workgroup where the correction is not folded in: 5 instead of 4 first-sweep rows
     // per 3 instead of 2 outputs, 167 VGPRs (still 3 workgroups/CU): 0.86 -> 0.79 ms per pair at 513^3
     static const int tyo_env = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
     const int tyo = j2_tyo_for(tpr, tyo_env);
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g, tpr, tyo == 3 ? 3 : 2);
+    const int nblocks = nby * nbz, grid = ((ncopy * nblocks + 7) / 8) * 8;
+    const bool damped = (omega != (T)1), nt = stream_level(g, sizeof(T));
     const int nby3 = (g.ny + 2) / 3, grid3 = ((ncopy * nby3 * nbz + 7) / 8) * 8;
 #define MG_J2K(TPR, D, N, Z) \
     do { \
@@ -811,10 +818,10 @@ void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
     const int tpr = (g.nx - 1) / V;
     const int ncopy = (dup > 0 && !coarse) ? 2 : 1;
     if (coarse) dup = 0;   // the folding variant only runs on whole levels
-    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g, tpr);
-    const int nblocks = nby * nbz, grid = ((ncopy * nblocks + 7) / 8) * 8;
     static const int tyo_env = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
     const int tyo = j2_tyo_for(tpr, tyo_env);
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g, tpr, (tyo == 3 && !coarse) ? 3 : 2);
+    const int nblocks = nby * nbz, grid = ((ncopy * nblocks + 7) / 8) * 8;
     const int nby3 = (g.ny + 2) / 3, grid3 = ((ncopy * nby3 * nbz + 7) / 8) * 8;
 #define MG_RB2(TPR) \
     do { \
@@ -846,14 +853,24 @@ bool jacobi2_corr_ok(const Geom &gf, const Geom &gc)
            gf.nz == 2 * gc.nz - 1 && gc.gz0 == 0 && gc.gnz == gc.nz;
 }
 
+// the same on the pieces of a z-slab (both levels distributed, the coarse slab = the planes that coincide with the fine slab's):
+// the coarse correction is addressed by global plane index, its two ghost planes either side must be valid
+template <typename T>
+bool jacobi2_corr_slab_ok(const Geom &gf, const Geom &gc)
+{
+    static const bool enabled = [] { const char *e = getenv("MG_FUSED_PROLONG_SLAB"); return !(e && e[0] == '0'); }();
+    return enabled && jacobi2_slab_ok<T>(gf) && gc.dim == 3 && gf.nx == 2 * gc.nx - 1 && gf.ny == 2 * gc.ny - 1 &&
+           gf.gnz == 2 * gc.gnz - 1 && gf.gz0 == 2 * gc.gz0 && (gf.nz == 2 * gc.nz || gf.nz == 2 * gc.nz - 1) && gc.nz >= 2;
+}
+
 template <typename T>
 void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u,
-                         const T *coarse, const T *rhs, T *out)
+                         const T *coarse, const T *rhs, T *out, int dup)
 {
     constexpr int V = VecOf<T>::V;
     const int tpr = (g.nx - 1) / V;
-    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g, tpr);
-    const int nblocks = nby * nbz, grid = ((nblocks + 7) / 8) * 8;
+    const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g, tpr, 2);
+    const int nblocks = nby * nbz, grid = (((dup > 0 ? 2 : 1) * nblocks + 7) / 8) * 8;
     const bool damped = (omega != (T)1);
     static const int minw_env = [] { const char *e = getenv("MG_J2C_MINW"); return e ? atoi(e) : 0; }();
     // fp32 (four floats per lane, three coarse values per row) needs 180 VGPRs: held to 168 it spills 12 of them and runs
@@ -862,11 +879,11 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
 #define MG_J2C(TPR) \
     do { \
         if (minw == 2) { \
-            if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true, false, false, 2, 2>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 0); \
-            else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, false, false, 2, 2>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 0); \
+            if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true, false, false, 2, 2>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, dup); \
+            else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, false, false, 2, 2>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, dup); \
         } else { \
-            if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 0); \
-            else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, 0); \
+            if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, dup); \
+            else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, dup); \
         } \
     } while (0)
     switch (tpr) {
@@ -882,8 +899,10 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
 
 template bool jacobi2_corr_ok<double>(const Geom &, const Geom &);
 template bool jacobi2_corr_ok<float>(const Geom &, const Geom &);
-template void launch_jacobi2_corr<double>(hipStream_t, const Geom &, const Geom &, const Coef<double> &, double, const double *, const double *, const double *, double *);
-template void launch_jacobi2_corr<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, float, const float *, const float *, const float *, float *);
+template void launch_jacobi2_corr<double>(hipStream_t, const Geom &, const Geom &, const Coef<double> &, double, const double *, const double *, const double *, double *, int);
+template void launch_jacobi2_corr<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, float, const float *, const float *, const float *, float *, int);
+template bool jacobi2_corr_slab_ok<double>(const Geom &, const Geom &);
+template bool jacobi2_corr_slab_ok<float>(const Geom &, const Geom &);
 template bool jacobi2_ok<double>(const Geom &);
 template bool jacobi2_ok<float>(const Geom &);
 template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *, bool, int);

@@ -35,7 +35,9 @@ template <typename T> bool jacobi2_slab_ok(const Geom &slab);
 template <typename T> bool jacobi2_corr_ok(const Geom &gf, const Geom &gc);
 template <typename T>
 void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u,
-                         const T *coarse, const T *rhs, T *out);
+                         const T *coarse, const T *rhs, T *out, int dup_planes = 0);
+// on the pieces of a z-slab: g = the piece, gc = the WHOLE coarse slab, coarse = its local plane 0 (two valid ghost planes either side)
+template <typename T> bool jacobi2_corr_slab_ok(const Geom &gf, const Geom &gc);
 // zebra line Gauss-Seidel along y: one colour pass; cp_den = the 2*ny factors of zebra_line_factors(cy, cd, ny) (device)
 template <typename T>
 void launch_zebra_y(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u, const T *rhs, T *dp,

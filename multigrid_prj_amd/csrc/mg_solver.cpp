@@ -633,6 +633,23 @@ bool Solver::can_skip_zeroing(int level) const
 
 // true when the V-cycle's prolong-add into `level` can be folded into the first post-smoothing pair
 // (k_jacobi2<CORR>): out = J(J(u + P e)) without ever storing u + P e
+static Geom slab_gate_geom(const Level &L);
+static bool depth2_enabled();
+
+// the same on two consecutive distributed levels (Jacobi, two ghost planes): every piece of the slab pair folds P e in
+template <typename T>
+bool Solver::can_fold_prolong_slab(int level) const
+{
+    static const bool enabled = [] { const char *e = getenv("MG_FUSED_PROLONG"); return !(e && e[0] == '0'); }();
+    if (!enabled || level + 1 >= d_.levels || !lv_[level].dist || !lv_[level + 1].dist) return false;
+    if (d_.smoother != MG_SMOOTH_JACOBI || d_.nu_post < 2 || !depth2_enabled() || lv_[level + 1].gh < 2 || lv_[level + 1].nz_min < 2) return false;
+    // the same answer on every rank: the gate looks at the thinnest slabs, whose z-relation holds like everybody's
+    Geom gf = slab_gate_geom(lv_[level]), gc = slab_gate_geom(lv_[level + 1]);
+    gf.nz = 2 * gc.nz;
+    return jacobi2_slab_ok<T>(slab_gate_geom(lv_[level])) && jacobi2_corr_slab_ok<T>(gf, gc) &&
+           jacobi2_corr_slab_ok<T>(lv_[level].g, lv_[level + 1].g);
+}
+
 template <typename T>
 bool Solver::can_fold_prolong(int level) const
 {
@@ -725,7 +742,7 @@ int Solver::refresh_rhs_halo(int level)
 // per neighbour and pair instead of two, three launches instead of five; the interior output planes 2 .. nz-3 need no
 // ghost plane at all and run while the halo moves. Same arithmetic per point => same bits as one GPU.
 template <typename T>
-int Solver::pair_on_slab2_t(int level, bool rb)
+int Solver::pair_on_slab2_t(int level, bool rb, int corr_level)
 {
     Level &L = lv_[level];
     const Geom &g = L.g;
@@ -734,9 +751,14 @@ int Solver::pair_on_slab2_t(int level, bool rb)
     T *px = ptr<T>(MG_ARR_U, level), *pr = ptr<T>(MG_ARR_RHS, level), *pt = ptr<T>(MG_ARR_TMP, level);
     const long long pl = g.plane;
     // dup > 0: the same piece once more, `dup` planes further up, in the same launch
+    // corr_level >= 0 (Jacobi): the pair also applies the coarse correction, out = J(J(u + P e)): e's two ghost planes either
+    // side come first (the separate prolongation fetched one), then every piece is the folding kernel
+    const T *pe = corr_level >= 0 ? ptr<T>(MG_ARR_U, corr_level) : (const T *)nullptr;
+    if (corr_level >= 0) MG_TRY(exchange(MG_ARR_U, corr_level, 2));
     auto fused = [&](const Geom &gs, long long off, int dup = 0, hipStream_t st = nullptr) {
         if (!st) st = stream_;
-        if (rb) launch_rb_fused<T>(st, gs, c, px + off, pr + off, pt + off, (const T *)nullptr, gs, dup);
+        if (pe) launch_jacobi2_corr<T>(st, gs, lv_[corr_level].g, c, om, px + off, pe, pr + off, pt + off, dup);
+        else if (rb) launch_rb_fused<T>(st, gs, c, px + off, pr + off, pt + off, (const T *)nullptr, gs, dup);
         else launch_jacobi2<T>(st, gs, c, om, px + off, pr + off, pt + off, false, dup);
     };
     static const bool one_boundary_launch = [] { const char *e = getenv("MG_MERGE_BOUNDARY"); return !(e && e[0] == '0'); }();
@@ -837,7 +859,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
                     launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level), true);
                     std::swap(L.base[ax], L.base[MG_ARR_TMP]);
                 } else {
-                    MG_TRY(pair_on_slab2_t<T>(level, false));
+                    MG_TRY(pair_on_slab2_t<T>(level, false, s == 0 ? corr_level : -1));
                 }
                 s++; launches += 1;   // counted as ONE segment: exchange + interior + boundary launches
                 continue;
@@ -1244,7 +1266,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         const bool skip0 = can_skip_zeroing<T>(l + 1);
         if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
         MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
-        fold = can_fold_prolong<T>(l);
+        fold = can_fold_prolong<T>(l) || can_fold_prolong_slab<T>(l);
         if (!fold) {
             if (prof) MG_TRY(prof_begin(l));
             MG_TRY(prolong_t<T>(l + 1, 1, MG_ARR_U, MG_ARR_U));

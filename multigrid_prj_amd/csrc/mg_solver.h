@@ -99,8 +99,9 @@ private:
     template <typename T> int smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero = false,
                                        int corr_level = -1, bool e_scratch = false);
     template <typename T> bool can_fold_prolong(int level) const;
+    template <typename T> bool can_fold_prolong_slab(int level) const;   // both levels distributed: the slab pair folds P e in
     template <typename T> int pair_on_slab_t(int level, bool rb);
-    template <typename T> int pair_on_slab2_t(int level, bool rb);   // depth-2 ghosts: one exchange, the fused kernel on the whole slab
+    template <typename T> int pair_on_slab2_t(int level, bool rb, int corr_level = -1);   // depth-2 ghosts: one exchange, the fused kernel on the whole slab
     template <typename T> int resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs);
     int refresh_rhs_halo(int level);
     template <typename T> bool can_skip_zeroing(int level) const;

@@ -39,12 +39,16 @@ def main():
         s.set_rhs(b)
         s.cycle()                      # the first cycle also sends the right-hand side's ghost planes once
         g0, b0 = s.comm_stats()
+        s.profile_begin()              # which kind of finest-level launches the remaining cycles make
         for _ in range(cycles - 1):
             s.cycle()
         g1, b1 = s.comm_stats()
+        s.profile_end()
+        kinds = {k: s.profile_get(getattr(capi, "PROF_" + k))[1] for k in ("SMOOTH", "SMOOTH_PROLONG", "PROLONG")}
         hist, _ = s.solve(0.0, 2)
         u = s.get_solution()
-        extra = dict(groups_per_cycle=(g1 - g0) / max(cycles - 1, 1), bytes_per_cycle=(b1 - b0) / max(cycles - 1, 1))
+        extra = dict(groups_per_cycle=(g1 - g0) / max(cycles - 1, 1), bytes_per_cycle=(b1 - b0) / max(cycles - 1, 1),
+                     fold_launches=kinds["SMOOTH_PROLONG"], prolong_launches=kinds["PROLONG"], smooth_launches=kinds["SMOOTH"])
         if case.get("check_e"):
             # the public mg_smooth on a distributed level must leave the caller's E array alone (inside the
             # V-cycle the fused pair uses E as scratch; the API call may not) and still equal the fused result

@@ -239,6 +239,34 @@ def test_hip_distributed_two_ghost_planes_halve_the_exchanges(rb, dtype, tmp_pat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,n,levels,dtype", [(2, 257, 5, 0), (3, 257, 5, 0), (2, 129, 4, 0), (2, 257, 5, 1)])
+def test_hip_distributed_prolongation_fold_on_slabs(world, n, levels, dtype, tmp_path):
+    """Two consecutive distributed levels: the post-smoothing pair of the finer one applies the coarse correction itself,
+    J(J(u + P e)) on every piece of the slab (interior, merged boundary launch) with e's ghost planes two deep -- no separate
+    prolongation launch on level 0 -- and the result keeps the bits of the separate prolongation, of one GPU and of the oracle."""
+    from multigrid_prj_amd import capi
+    case, desc, b = _case(tmp_path, n, levels, 1, cycles=3, dtype=dtype)
+    desc["dist_min_n"] = 65           # 257: 257^3, 129^3, 65^3 distributed; 129: 129^3, 65^3
+    case["desc"] = desc
+    res = {}
+    for fold in ("1", "0"):
+        u, hists, fg = _run_ranks("hip", world, case, tmp_path, extra_env={"MG_FUSED_PROLONG_SLAB": fold})
+        assert fg >= 2
+        res[fold] = (u, [int(p["fold_launches"]) for p in _run_ranks.last_parts], [int(p["prolong_launches"]) for p in _run_ranks.last_parts])
+    assert all(f == 2 for f in res["1"][1]) and all(p == 0 for p in res["1"][2]), res["1"][1:]   # two profiled cycles, folded
+    assert all(f == 0 for f in res["0"][1]) and all(p == 2 for p in res["0"][2]), res["0"][1:]   # ... separate prolongation
+    assert np.array_equal(res["1"][0], res["0"][0])
+    u_ref, _ = _oracle(desc, b, case["cycles"])
+    assert np.array_equal(res["1"][0], u_ref)
+    with capi.Solver(capi.make_desc(**desc)) as s:
+        s.set_rhs(b)
+        for _ in range(case["cycles"]):
+            s.cycle()
+        s.solve(0.0, 2)
+        assert np.array_equal(res["1"][0], s.get_solution())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rb", [False, True])
 def test_hip_distributed_public_smooth_leaves_e_alone(rb, tmp_path):
     """mg_smooth(level, ..., U, RHS) on a distributed level: the caller's E array survives (the V-cycle's
