@@ -75,6 +75,15 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
 // dup_kc > 0 (gc.nz must be 1): a second single coarse plane dup_kc coarse planes further up (its fine planes start 2 dup_kc
 // further up and there are dup_nzf of them) in the same launch -- the two boundary pieces of a z-slab
 
+// launch-bound levels (65^3 and below), V(2,2) Jacobi, whole 3-D levels (mg_small_levels.hip): the three launches either side
+// of the coarser levels in one each -- u_out = J(J(0)), coarse = R(rhs - A u_out)  /  out = J(J(u + P e))
+template <typename T> bool small_fused_ok(const Geom &gf, const Geom &gc);
+template <typename T>
+void launch_small_pre_rr(hipStream_t s, const Geom &gf, const Geom &gc, const Coef<T> &c, T omega, const T *rhs, T *u_out, T *coarse);
+template <typename T>
+void launch_small_prolong_post(hipStream_t s, const Geom &gf, const Geom &gc, const Coef<T> &c, T omega, const T *u, const T *e,
+                               const T *rhs, T *out);
+
 // one colour half-sweep of red-black Gauss-Seidel, in place
 template <typename T>
 void launch_rbgs_colour(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u,

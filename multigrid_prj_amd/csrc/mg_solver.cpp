@@ -1224,12 +1224,28 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
     const bool fuse_rr_slab = mine && lv_[l].dist && d_.restriction == MG_RESTRICT_FULLW && depth2_enabled() &&
                               resid_restrict_slab_ok<T>(lv_[l].g, gc_slab);
     const bool prof = profiling_ && l == 0 && mine;
-    if (mine) {
+    // launch-bound levels (65^3 and below; rows too narrow for the fused pair): V(2,2) Jacobi with full weighting runs as ONE
+    // launch either side of the coarser levels -- J(J(0)) + residual + restriction, and J(J(u + P e)) (mg_small_levels.hip)
+    const bool small = mine && !prof && !stage_fn_ && !lv_[l].dist && lv_[l + 1].present && !lv_[l + 1].dist &&
+                       d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre == 2 && d_.nu_post == 2 && d_.restriction == MG_RESTRICT_FULLW &&
+                       !jacobi2_ok<T>(lv_[l].g) && small_fused_ok<T>(lv_[l].g, lv_[l + 1].g);
+    const bool small_pre = small && u_zero;   // the zero guess is part of the fused kernel's contract
+    if (small_pre) {
+        lv_[l + 1].rhs_halo_ok = false;
+        launch_small_pre_rr<T>(stream_, lv_[l].g, lv_[l + 1].g, coef_of<T>(lv_[l]), (T)d_.omega, ptr<T>(MG_ARR_RHS, l),
+                               ptr<T>(MG_ARR_U, l), ptr<T>(MG_ARR_RHS, l + 1));
+        MG_HIP(hipGetLastError());
+        const bool skip0 = can_skip_zeroing<T>(l + 1);
+        if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
+        MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
+    } else if (mine) {
         MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero, -1, true));
         if (prof) MG_TRY(prof_begin(l));
         if (!fuse_rr && !fuse_rr_slab) MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
     }
-    if (lv_[l].dist && !lv_[l + 1].dist) {  // l == T_: restrict locally, gather the coarse rhs on rank 0
+    if (small_pre) {
+        // residual, restriction and the coarser levels are done
+    } else if (lv_[l].dist && !lv_[l + 1].dist) {  // l == T_: restrict locally, gather the coarse rhs on rank 0
         if (fuse_rr_slab) {
             MG_TRY(resid_restrict_on_slab_t<T>(l, stage_g_, stageptr<T>(0)));
         } else if (d_.restriction == MG_RESTRICT_FULLW) {
@@ -1267,13 +1283,18 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
         MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
         fold = can_fold_prolong<T>(l) || can_fold_prolong_slab<T>(l);
-        if (!fold) {
+        if (!fold && !small) {
             if (prof) MG_TRY(prof_begin(l));
             MG_TRY(prolong_t<T>(l + 1, 1, MG_ARR_U, MG_ARR_U));
             if (prof) MG_TRY(prof_end(l, MG_PROF_PROLONG, 1, 1));
         }
     }
-    if (mine) MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS, false, fold ? l + 1 : -1, true));
+    if (small) {   // prolong-add and both post-smoothing sweeps in one launch; the result lands in TMP like a sweep's
+        launch_small_prolong_post<T>(stream_, lv_[l].g, lv_[l + 1].g, coef_of<T>(lv_[l]), (T)d_.omega, ptr<T>(MG_ARR_U, l),
+                                     ptr<T>(MG_ARR_U, l + 1), ptr<T>(MG_ARR_RHS, l), ptr<T>(MG_ARR_TMP, l));
+        MG_HIP(hipGetLastError());
+        std::swap(lv_[l].base[MG_ARR_U], lv_[l].base[MG_ARR_TMP]);
+    } else if (mine) MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS, false, fold ? l + 1 : -1, true));
     return MG_OK;
 }
 
