@@ -122,7 +122,7 @@ void launch_correct(hipStream_t s, const Geom &g, T *u, T *e);
 template <typename T>
 void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, int smoother,
                          T *x, T *tmp, const T *rhs, int maxit, double tol, int fixed,
-                         CoarseOut *d_out);
+                         CoarseOut *d_out, bool x_is_zero = false);
 
 }  // namespace mg
 #endif

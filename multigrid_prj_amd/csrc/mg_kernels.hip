@@ -832,7 +832,7 @@ template <int SEG> struct CoarseRowsThreads { static constexpr int value = SEG >
 
 template <typename T, int DIM, int SEG>
 __global__ __launch_bounds__(CoarseRowsThreads<SEG>::value) void k_coarse_jacobi_rows(Geom g, Coef<T> c, T omega, T *x, const T *rhs,
-                                                            int maxit, double tol, int fixed, CoarseOut *out, int skip)
+                                                            int maxit, double tol, int fixed, CoarseOut *out, int skip, int zero_x)
 {
     // Threads own INTERIOR points only, in full runs of SEG:
     // the iteration body has no predicates and no boundary selects, so the SEG points of a thread
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(CoarseRowsThreads<SEG>::value) void k_coarse_jacobi
     double sqb = 0.;
     for (int q = tid; q < total; q += nthr) {
         const long long gi = dense_to_global(q);
-        cur[q] = x[gi];
+        cur[q] = zero_x ? (T)0 : x[gi];   // zero_x: the initial guess is zero (the caller skipped the memset of x)
         const double t = (double)rhs[gi];
         sqb += t * t;
     }
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(CoarseRowsThreads<SEG>::value) void k_coarse_jacobi
         xv[k] = 0; bv[k] = 0;
         if (active) {
             const long long gi = lidx(g, z, y, x0 + k);
-            xv[k] = x[gi]; bv[k] = rhs[gi];
+            xv[k] = zero_x ? (T)0 : x[gi]; bv[k] = rhs[gi];
         }
     }
     int parity = 0;
@@ -1583,7 +1583,7 @@ static bool try_launch_coarse_lds(hipStream_t s, const Geom &g, const Coef<T> &c
 
 template <typename T, int DIM, int SEG>
 static bool try_launch_coarse_jacobi_rows(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, T *x,
-                                          const T *rhs, int maxit, double tol, int fixed, CoarseOut *d_out)
+                                          const T *rhs, int maxit, double tol, int fixed, CoarseOut *d_out, int zero_x)
 {
     const size_t total = (size_t)g.nx * g.ny * g.nz;
     // MG_COARSE_SKIP = sweeps between two norm tests (1 = test after every sweep, the plain loop)
@@ -1602,13 +1602,13 @@ static bool try_launch_coarse_jacobi_rows(hipStream_t s, const Geom &g, const Co
                                 150 * 1024) != hipSuccess) return false;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(((threads + 63) / 64) * 64), bytes, s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, skip);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(((threads + 63) / 64) * 64), bytes, s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, skip, zero_x);
     return true;
 }
 
 template <typename T, int DIM>
 static bool try_launch_coarse_jacobi(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, T *x, const T *rhs,
-                                     int maxit, double tol, int fixed, CoarseOut *d_out)
+                                     int maxit, double tol, int fixed, CoarseOut *d_out, int zero_x)
 {
     static const bool enabled = [] { const char *e = getenv("MG_COARSE_ROWS"); return !(e && e[0] == '0'); }();
     if (!enabled || g.ny < 3 || (DIM == 3 && g.nz < 3)) return false;
@@ -1627,10 +1627,10 @@ static bool try_launch_coarse_jacobi(hipStream_t s, const Geom &g, const Coef<T>
         break;
     }
     switch (best) {
-    case 4: return try_launch_coarse_jacobi_rows<T, DIM, 4>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
-    case 5: return try_launch_coarse_jacobi_rows<T, DIM, 5>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
-    case 7: return try_launch_coarse_jacobi_rows<T, DIM, 7>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
-    case 8: return try_launch_coarse_jacobi_rows<T, DIM, 8>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out);
+    case 4: return try_launch_coarse_jacobi_rows<T, DIM, 4>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, zero_x);
+    case 5: return try_launch_coarse_jacobi_rows<T, DIM, 5>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, zero_x);
+    case 7: return try_launch_coarse_jacobi_rows<T, DIM, 7>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, zero_x);
+    case 8: return try_launch_coarse_jacobi_rows<T, DIM, 8>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, zero_x);
     default: return false;  // other widths keep the generic LDS kernel
     }
 }
@@ -1656,12 +1656,19 @@ static bool try_launch_coarse_gs_rows2d(hipStream_t s, const Geom &g, const Coef
 template <typename T>
 void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, int smoother,
                          T *x, T *tmp, const T *rhs, int maxit, double tol, int fixed,
-                         CoarseOut *d_out)
+                         CoarseOut *d_out, bool x_is_zero)
 {
+    // x_is_zero: the solve starts from the zero guess and the caller has NOT cleared x: the row-segment Jacobi kernel takes the
+    // guess as a flag (a memset launch less per cycle); every other kernel gets its x cleared here
+    if (x_is_zero && smoother == 1 && g.gz0 == 0 && g.gnz == g.nz) {
+        if (g.dim == 3 ? try_launch_coarse_jacobi<T, 3>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, 1)
+                       : try_launch_coarse_jacobi<T, 2>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, 1)) return;
+    }
+    if (x_is_zero) (void)hipMemsetAsync(x, 0, (size_t)g.nz * (size_t)g.plane * sizeof(T), s);
     // LDS-resident when the three arrays fit one CU's LDS, global-memory loop otherwise
     if (smoother == 1 && g.gz0 == 0 && g.gnz == g.nz) {  // Jacobi: the row-segment kernel
-        if (g.dim == 3 ? try_launch_coarse_jacobi<T, 3>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out)
-                       : try_launch_coarse_jacobi<T, 2>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out)) return;
+        if (g.dim == 3 ? try_launch_coarse_jacobi<T, 3>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, 0)
+                       : try_launch_coarse_jacobi<T, 2>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, 0)) return;
     }
     if (smoother == 0 && try_launch_coarse_gs_rows2d<T>(s, g, c, x, rhs, maxit, tol, fixed, d_out)) return;
     if (g.dim == 3) {
@@ -1692,7 +1699,7 @@ void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega
     template void launch_prolong<T>(hipStream_t, const Geom &, const Geom &, const T *, T *, bool); \
     template void launch_correct<T>(hipStream_t, const Geom &, T *, T *);                          \
     template void launch_coarse_solve<T>(hipStream_t, const Geom &, const Coef<T> &, T, int, T *,  \
-                                         T *, const T *, int, double, int, CoarseOut *);
+                                         T *, const T *, int, double, int, CoarseOut *, bool);
 MG_INSTANTIATE(double)
 MG_INSTANTIATE(float)
 

@@ -1115,23 +1115,23 @@ int Solver::correct(int arr_u, int arr_e)
 }
 
 template <typename T>
-int Solver::coarse_ex_t(int level, int ax, int ar, int smoother, int maxit, double tol, int fixed)
+int Solver::coarse_ex_t(int level, int ax, int ar, int smoother, int maxit, double tol, int fixed, bool x_zero)
 {
     Level &L = lv_[level];
     launch_coarse_solve<T>(stream_, L.g, coef_of<T>(L), (T)d_.omega, smoother, ptr<T>(ax, level),
-                           ptr<T>(MG_ARR_TMP, level), ptr<T>(ar, level), maxit, tol, fixed, d_coarse_);
+                           ptr<T>(MG_ARR_TMP, level), ptr<T>(ar, level), maxit, tol, fixed, d_coarse_, x_zero);
     MG_HIP(hipGetLastError());
     return MG_OK;
 }
 
 template <typename T>
-int Solver::coarse_t(int level, int ax, int ar)
+int Solver::coarse_t(int level, int ax, int ar, bool x_zero)
 {
     // the coarsest-grid solver of a zebra hierarchy smooths with red-black Gauss-Seidel (mg_desc.h)
     const int sm = coarse_smoother_of(d_.smoother);
-    if (lock_iters_ >= 0) return coarse_ex_t<T>(level, ax, ar, sm, lock_iters_, d_.coarse_tol, 1);
+    if (lock_iters_ >= 0) return coarse_ex_t<T>(level, ax, ar, sm, lock_iters_, d_.coarse_tol, 1, x_zero);
     return coarse_ex_t<T>(level, ax, ar, sm, d_.coarse_maxit, d_.coarse_tol,
-                          d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0);
+                          d_.coarse_mode == MG_COARSE_FIXED ? 1 : 0, x_zero);
 }
 
 int Solver::coarse_solve(int level, int arr_x, int arr_rhs, mg_cycle_stats *st)
@@ -1181,13 +1181,15 @@ int Solver::coarse_full_t()
     return MG_OK;
 }
 
+// x_zero: the initial guess is zero and the array has NOT been cleared (the LDS Jacobi solver takes that as a flag)
 template <typename T>
-int Solver::coarse_level_t(int l, int ax, int ar)
+int Solver::coarse_level_t(int l, int ax, int ar, bool x_zero)
 {
     Level &L = lv_[l];
     if (!L.present) return MG_OK;  // this rank holds nothing of the level (gathered on rank 0)
     const long long pts = (long long)L.g.nx * L.g.ny * L.g.gnz;
     const bool big = pts > 32768;  // e.g. the 17 x 17 x 513 coarsest grid of a semi-coarsened hierarchy
+    if (x_zero && ((big && d_.coarse_mode == MG_COARSE_FIXED) || L.dist)) { MG_TRY(zero_array(ax, l)); x_zero = false; }
     if (big && d_.coarse_mode == MG_COARSE_FIXED) {
         MG_TRY(smooth_t<T>(l, coarse_smoother_of(d_.smoother), d_.coarse_maxit, ax, ar, false, -1,
                            d_.cycle == MG_CYCLE_V));
@@ -1202,7 +1204,7 @@ int Solver::coarse_level_t(int l, int ax, int ar)
         MG_TRY(scatter_T(1, ax));
         return MG_OK;
     }
-    return coarse_t<T>(l, ax, ar);
+    return coarse_t<T>(l, ax, ar, x_zero);
 }
 
 // Standard V(nu_pre, nu_post) (extension, BASELINE configs 2-4). Slab-decomposed runs: levels
@@ -1215,7 +1217,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
     const int L = d_.levels;
     const bool mine = lv_[l].present;
     bool fold = false;  // prolong-add folded into the post-smoothing pair
-    if (l == L - 1) return coarse_level_t<T>(l, MG_ARR_U, MG_ARR_RHS);
+    if (l == L - 1) return coarse_level_t<T>(l, MG_ARR_U, MG_ARR_RHS, u_zero);
     // fused residual + full weighting when both levels live whole on this rank
     const bool fuse_rr = mine && d_.restriction == MG_RESTRICT_FULLW && !lv_[l].dist && lv_[l + 1].present &&
                          resid_restrict_fast_ok<T>(lv_[l].g, lv_[l + 1].g);
@@ -1235,7 +1237,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         launch_small_pre_rr<T>(stream_, lv_[l].g, lv_[l + 1].g, coef_of<T>(lv_[l]), (T)d_.omega, ptr<T>(MG_ARR_RHS, l),
                                ptr<T>(MG_ARR_U, l), ptr<T>(MG_ARR_RHS, l + 1));
         MG_HIP(hipGetLastError());
-        const bool skip0 = can_skip_zeroing<T>(l + 1);
+        const bool skip0 = can_skip_zeroing<T>(l + 1) || l + 1 == L - 1;   // the coarsest-grid solver takes the zero guess as a flag
         if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
         MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
     } else if (mine) {
@@ -1258,7 +1260,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         if (prof) MG_TRY(prof_end(l, MG_PROF_RESID_RESTRICT, 1, 2));
         MG_TRY(gather_S(MG_ARR_RHS));
         if (lv_[l + 1].present) {
-            const bool skip0 = can_skip_zeroing<T>(l + 1);
+            const bool skip0 = can_skip_zeroing<T>(l + 1) || l + 1 == L - 1;
             if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
             MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
         }
@@ -1279,7 +1281,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
             MG_TRY(restrict_t<T>(l, d_.restriction, MG_ARR_TMP, MG_ARR_RHS));
         }
         if (prof) MG_TRY(prof_end(l, MG_PROF_RESID_RESTRICT, 1, fuse_rr ? 1 : 2));
-        const bool skip0 = can_skip_zeroing<T>(l + 1);
+        const bool skip0 = can_skip_zeroing<T>(l + 1) || l + 1 == L - 1;   // the coarsest-grid solver takes the zero guess as a flag
         if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
         MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
         fold = can_fold_prolong<T>(l) || can_fold_prolong_slab<T>(l);

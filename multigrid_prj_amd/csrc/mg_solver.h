@@ -113,7 +113,7 @@ private:
     template <typename T> int coarse_full_t();
     // coarse "solve" of level l: persistent one-workgroup kernel, or -- when the level is too big
     // for one workgroup and the mode is MG_COARSE_FIXED -- coarse_maxit regular sweeps
-    template <typename T> int coarse_level_t(int l, int ax, int ar);  // coarse solve of a still-distributed coarsest level, gathered
+    template <typename T> int coarse_level_t(int l, int ax, int ar, bool x_zero = false);  // coarse solve of a still-distributed coarsest level, gathered
     int exchange(int which, int level, int depth = 1);        // `depth` ghost planes <-> z-neighbours (on the main stream)
     // the same on the comm stream, after the main stream's work so far; record = false: the caller puts more work that needs the halo
     // on the comm stream (the boundary pieces of a slab operation) and records the event itself with halo_work_done()
@@ -131,8 +131,8 @@ private:
     int scatter_T(int fullk, int which);         // full_[fullk] on rank 0 -> slabs of level T_
     int allreduce(double *dptr, int n);
     template <typename T> T *fullptr(int k) const { return reinterpret_cast<T *>(full_[k]) + gfull_.plane; }
-    template <typename T> int coarse_t(int level, int ax, int ar);
-    template <typename T> int coarse_ex_t(int level, int ax, int ar, int smoother, int maxit, double tol, int fixed);
+    template <typename T> int coarse_t(int level, int ax, int ar, bool x_zero = false);
+    template <typename T> int coarse_ex_t(int level, int ax, int ar, int smoother, int maxit, double tol, int fixed, bool x_zero = false);
     template <typename T> int cycle_enqueue_t();
     template <typename T> int vcycle_rec_t(int l, bool u_zero = false);
     int cycle_enqueue();
