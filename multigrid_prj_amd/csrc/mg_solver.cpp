@@ -342,6 +342,7 @@ T *Solver::ptr(int which, int level) const
 // a third of the whole solve of the reference's own case.
 int Solver::stage_rows(int which, int level, void *host, bool to_device)
 {
+    pair_on_comm_level_ = -1;
     MG_HIP(hipSetDevice(device_));
     const Level &L = lv_[level];
     const size_t es = esize(), row = (size_t)L.g.nx * es, prow = (size_t)L.g.pitch * es;
@@ -397,6 +398,7 @@ int Solver::get_array(int which, int level, void *host)
 
 int Solver::zero_array(int which, int level)
 {
+    pair_on_comm_level_ = -1;
     if (!check_arr(which, level, "mg_zero_array")) return MG_ERR_BAD_ARG;
     if (which == MG_ARR_RHS) lv_[level].rhs_halo_ok = false;
     MG_HIP(hipMemsetAsync(lv_[level].base[which], 0, lv_[level].alloc_elems * esize(), stream_));
@@ -742,7 +744,10 @@ int Solver::refresh_rhs_halo(int level)
 // per neighbour and pair instead of two, three launches instead of five; the interior output planes 2 .. nz-3 need no
 // ghost plane at all and run while the halo moves. Same arithmetic per point => same bits as one GPU.
 template <typename T>
-int Solver::pair_on_slab2_t(int level, bool rb, int corr_level)
+// u_halo_ok: U's two ghost planes either side already hold the neighbours' current planes (the residual + restriction of this
+// cycle fetched them and nothing has written U since -- true for the folding pair, which reads the uncorrected u): no exchange,
+// and with nothing to hide behind an interior launch the whole slab is ONE launch.
+int Solver::pair_on_slab2_t(int level, bool rb, int corr_level, bool u_halo_ok)
 {
     Level &L = lv_[level];
     const Geom &g = L.g;
@@ -763,7 +768,10 @@ int Solver::pair_on_slab2_t(int level, bool rb, int corr_level)
     };
     static const bool one_boundary_launch = [] { const char *e = getenv("MG_MERGE_BOUNDARY"); return !(e && e[0] == '0'); }();
     MG_TRY(refresh_rhs_halo(level));
-    if (!overlap_ || g.nz < 8) {
+    static const bool reuse_halo = [] { const char *e = getenv("MG_REUSE_HALO"); return !(e && e[0] == '0'); }();
+    if (u_halo_ok && reuse_halo) {
+        fused(g, 0);
+    } else if (!overlap_ || g.nz < 8) {
         MG_TRY(exchange(MG_ARR_U, level, 2));
         fused(g, 0);
     } else {
@@ -774,6 +782,7 @@ int Solver::pair_on_slab2_t(int level, bool rb, int corr_level)
         if (on_comm) {                       // the boundary planes follow the halo on its own stream, beside the interior launch
             fused(glo, 0, g.nz - 2, comm_stream_);
             MG_TRY(halo_work_done());
+            pair_on_comm_level_ = level;     // the planes the next exchange sends were written on the communication stream
         }
         fused(gi, 2 * pl);
         MG_TRY(exchange_end());
@@ -802,6 +811,8 @@ int Solver::resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs)
     const Coef<T> c = coef_of<T>(L);
     T *pu = ptr<T>(MG_ARR_U, level), *pr = ptr<T>(MG_ARR_RHS, level);
     MG_TRY(refresh_rhs_halo(level));
+    const int pair_level = pair_on_comm_level_;
+    pair_on_comm_level_ = -1;
     const bool semi = gf.gnz == gc.gnz;          // planes map one to one
     if (!overlap_ || gc.nz < 4 || semi) {
         MG_TRY(exchange(MG_ARR_U, level, 2));
@@ -810,7 +821,21 @@ int Solver::resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs)
         // coarse planes 1 .. nzc-2 read u on owned planes only: they run while the halo moves
         static const bool one_boundary_launch = [] { const char *e = getenv("MG_MERGE_BOUNDARY"); return !(e && e[0] == '0'); }();
         const bool on_comm = one_boundary_launch && boundary_on_comm_stream();
-        MG_TRY(exchange_begin(MG_ARR_U, level, 2, !on_comm));
+        static const bool early = [] { const char *e = getenv("MG_EARLY_EXCHANGE"); return !(e && e[0] == '0'); }();
+        if (on_comm && early && pair_level == level) {
+            // The planes to send (0, 1, nz-2, nz-1 of the pair's output) were written by the pair's boundary piece on the
+            // communication stream itself: the exchange starts at once, while the pair's interior launch is still running on
+            // the main stream; only the boundary piece below needs that launch's planes.
+            if (2 > L.gh || 2 > L.nz_min) { set_last_error("halo exchange deeper than the ghost planes / the thinnest slab"); return MG_ERR_BAD_ARG; }
+            P2POp ops[4];
+            const int n = halo_ops(MG_ARR_U, level, 2, ops);
+            int rc = post(ops, n, comm_stream_);
+            if (rc) { set_last_error("halo exchange failed"); return rc; }
+            MG_HIP(hipEventRecord(ev_ready_, stream_));
+            MG_HIP(hipStreamWaitEvent(comm_stream_, ev_ready_, 0));
+        } else {
+            MG_TRY(exchange_begin(MG_ARR_U, level, 2, !on_comm));
+        }
         Geom gc0 = gc; gc0.nz = 1;
         Geom gf0 = gf; gf0.nz = 2;
         const int kl = gc.nz - 1;                 // last coarse plane: fine planes 2 kl (and 2 kl + 1 unless it is the grid's top plane)
@@ -843,9 +868,10 @@ int Solver::resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs)
 // fused pair on a z-slab keeps its boundary planes' first sweep there. The public mg_smooth never passes it, so a
 // caller's E array is left alone (distributed levels then take exchanged single sweeps).
 template <typename T>
-int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero, int corr_level, bool e_scratch)
+int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero, int corr_level, bool e_scratch, bool u_halo_ok)
 {
     Level &L = lv_[level];
+    pair_on_comm_level_ = -1;
     Coef<T> c = coef_of<T>(L);
     const bool prof = profiling_ && level == 0 && sweeps > 0 && smoother != MG_SMOOTH_GS_LEX;
     int launches = 0;  // kernel launches of this call (a fused pair is one)
@@ -853,13 +879,14 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
     switch (smoother) {
     case MG_SMOOTH_JACOBI:
         for (int s = 0; s < sweeps; s++) {
+            pair_on_comm_level_ = -1;
             if (L.dist && depth2_enabled() && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps && jacobi2_slab_ok<T>(slab_gate_geom(L))) {
                 if (x_zero && s == 0) {  // zero guess on every rank: no halo of u to fetch at all, only the neighbours' rhs planes
                     MG_TRY(refresh_rhs_halo(level));
                     launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level), true);
                     std::swap(L.base[ax], L.base[MG_ARR_TMP]);
                 } else {
-                    MG_TRY(pair_on_slab2_t<T>(level, false, s == 0 ? corr_level : -1));
+                    MG_TRY(pair_on_slab2_t<T>(level, false, s == 0 ? corr_level : -1, s == 0 && u_halo_ok));
                 }
                 s++; launches += 1;   // counted as ONE segment: exchange + interior + boundary launches
                 continue;
@@ -898,6 +925,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
         break;
     case MG_SMOOTH_RBGS:
         for (int s = 0; s < sweeps; s++) {
+            pair_on_comm_level_ = -1;
             if (L.dist && depth2_enabled() && ax == MG_ARR_U && ar == MG_ARR_RHS && jacobi2_slab_ok<T>(slab_gate_geom(L)) && rb_slab_enabled()) {
                 MG_TRY(pair_on_slab2_t<T>(level, true));   // one-pass red-black sweep on the whole slab, two ghost planes
                 launches += 1;
@@ -1217,6 +1245,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
     const int L = d_.levels;
     const bool mine = lv_[l].present;
     bool fold = false;  // prolong-add folded into the post-smoothing pair
+    bool fold_slab = false;  // ... on the pieces of a slab: u itself stays as the residual + restriction saw it
     if (l == L - 1) return coarse_level_t<T>(l, MG_ARR_U, MG_ARR_RHS, u_zero);
     // fused residual + full weighting when both levels live whole on this rank
     const bool fuse_rr = mine && d_.restriction == MG_RESTRICT_FULLW && !lv_[l].dist && lv_[l + 1].present &&
@@ -1284,7 +1313,8 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         const bool skip0 = can_skip_zeroing<T>(l + 1) || l + 1 == L - 1;   // the coarsest-grid solver takes the zero guess as a flag
         if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
         MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
-        fold = can_fold_prolong<T>(l) || can_fold_prolong_slab<T>(l);
+        fold_slab = can_fold_prolong_slab<T>(l);
+        fold = can_fold_prolong<T>(l) || fold_slab;
         if (!fold && !small) {
             if (prof) MG_TRY(prof_begin(l));
             MG_TRY(prolong_t<T>(l + 1, 1, MG_ARR_U, MG_ARR_U));
@@ -1296,7 +1326,10 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
                                      ptr<T>(MG_ARR_U, l + 1), ptr<T>(MG_ARR_RHS, l), ptr<T>(MG_ARR_TMP, l));
         MG_HIP(hipGetLastError());
         std::swap(lv_[l].base[MG_ARR_U], lv_[l].base[MG_ARR_TMP]);
-    } else if (mine) MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS, false, fold ? l + 1 : -1, true));
+    } else if (mine) {
+        // the folding pair on a slab reads the uncorrected u, whose ghost planes this cycle's residual + restriction fetched
+        MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_post, MG_ARR_U, MG_ARR_RHS, false, fold ? l + 1 : -1, true, fold_slab && fuse_rr_slab));
+    }
     return MG_OK;
 }
 
@@ -1304,6 +1337,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
 template <typename T>
 int Solver::cycle_enqueue_t()
 {
+    pair_on_comm_level_ = -1;
     const int L = d_.levels;
     if (d_.cycle == MG_CYCLE_V) return vcycle_rec_t<T>(0);
     // --- reference sawtooth, include/multigrid.hpp:126-145 ---

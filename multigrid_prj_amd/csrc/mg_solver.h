@@ -97,11 +97,11 @@ private:
     // x_zero: the caller knows x == 0 (fresh coarse-level guess): the first Jacobi sweep of a
     // fast-path level then skips reading x (and the caller skips the memset)
     template <typename T> int smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x_zero = false,
-                                       int corr_level = -1, bool e_scratch = false);
+                                       int corr_level = -1, bool e_scratch = false, bool u_halo_ok = false);
     template <typename T> bool can_fold_prolong(int level) const;
     template <typename T> bool can_fold_prolong_slab(int level) const;   // both levels distributed: the slab pair folds P e in
     template <typename T> int pair_on_slab_t(int level, bool rb);
-    template <typename T> int pair_on_slab2_t(int level, bool rb, int corr_level = -1);   // depth-2 ghosts: one exchange, the fused kernel on the whole slab
+    template <typename T> int pair_on_slab2_t(int level, bool rb, int corr_level = -1, bool u_halo_ok = false);   // depth-2 ghosts: one exchange, the fused kernel on the whole slab
     template <typename T> int resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs);
     int refresh_rhs_halo(int level);
     template <typename T> bool can_skip_zeroing(int level) const;
@@ -119,6 +119,9 @@ private:
     // on the comm stream (the boundary pieces of a slab operation) and records the event itself with halo_work_done()
     int exchange_begin(int which, int level, int depth = 1, bool record = true);
     int halo_work_done();
+    // level whose U boundary planes were last written on the COMMUNICATION stream (by the boundary piece of a slab pair) with
+    // nothing touching U since: the next exchange of those planes needs no wait for the main stream. -1: none.
+    int pair_on_comm_level_ = -1;
     int halo_ops(int which, int level, int depth, P2POp *ops);
     int exchange_end();                          // main stream waits for the halo
     // Runs a stencil launch over a distributed level with the halo exchange of `arr_x` hidden
