@@ -288,17 +288,19 @@ static int j2_nbz(const Geom &g, int tpr, int tyo = 3)   // tyo: output rows per
 // copied): out = RB(u) in one pass over HBM instead of two (k_sweep3d<OP_RB> twice).
 // ZEROU: u is identically zero (the two pre-smoothing sweeps of a coarse level): nothing is loaded for it.
 // MINW: minimum waves per SIMD the register allocation is held to (3 = 168 VGPRs; 2 = 256: the fp32 folding variant spills otherwise)
+// VW: elements per lane (0 = the type's 16-byte vector). The fp32 folding variant runs with TWO floats per lane: with four it
+// needs 180 VGPRs (two waves per SIMD), with two the registers of a row halve and it keeps the occupancy of the fp64 kernel.
 template <typename T, int TPR, bool DAMPED, bool NTLOAD, bool CORR = false, bool RB = false, bool ZEROU = false, int TYO_ = J2_TYO,
-          int MINW = 3>
+          int MINW = 3, int VW = 0>
 __global__ __launch_bounds__(TPR, MINW) void k_jacobi2(Geom g, Coef<T> c, T omega, const T *__restrict__ u_,
                                                  const T *__restrict__ rhs_, T *__restrict__ out_, int nby, int nbz,
                                                  const T *__restrict__ coarse, Geom gc, int dup_planes)
 {
-    constexpr int V = VecOf<T>::V, TYO = TYO_, TYV = TYO + 2;
+    constexpr int V = VW ? VW : VecOf<T>::V, TYO = TYO_, TYV = TYO + 2;
     constexpr int CV = V / 2;  // coarse columns owned by this thread
     static_assert(!CORR || TYO == 2, "the correction assumes two output rows (y0 even)");
     constexpr int LP = TPR * V + 2 * V;  // LDS row: V pad | TPR*V values | tail column | pad
-    typedef typename VecOf<T>::type vec;
+    typedef T vec __attribute__((ext_vector_type(V)));
     __shared__ __align__(16) T lds[2][TYV][LP];
     // u values on the wave edges (first / last element of every wave's row segment), published one
     // plane ahead: the x-neighbour a wave's edge lane needs belongs to the neighbouring wave of the
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(TPR, MINW) void k_jacobi2(Geom g, Coef<T> c, T omeg
     // (The row's last thread reads up to gc.nx - 1 in fp64, one element of row padding beyond it in fp32.)
     constexpr int NR = CV + 1;
     const T hf = (T)0.5;
-    typedef T cwide __attribute__((ext_vector_type(16 / sizeof(T)), aligned(8)));
+    // (NR values rounded up to a power of two, aligned like the lane's first coarse column)
+    typedef T cwide __attribute__((ext_vector_type(NR <= 2 ? 2 : 4), aligned(CV * sizeof(T))));
     int ucrow[4];          // offsets of coarse rows yc0-1 .. yc0+2 (clamped into the grid): workgroup-uniform
     const int ic0 = CV * t;   // own first coarse column
     if (CORR) {
@@ -620,10 +623,10 @@ __global__ __launch_bounds__(TPR, MINW) void k_jacobi2(Geom g, Coef<T> c, T omeg
                         if (RB && (((x0 + e + y + gzo + q) & 1) == 0)) res[e] = vc[r][e];  // not black: unchanged
                     }
                     __builtin_nontemporal_store(res, (vec *)((out + (qo + urow[lr])) + x0));
-                    if (tailwave && lane >= 56) {
+                    constexpr int LINE = 128 / (int)sizeof(T), TLN = LINE / V;   // lanes that write the tail line
+                    if (tailwave && lane >= 64 - TLN) {
                         // column nx-1 (Dirichlet) as one full 128-byte line: value + zero padding
-                        const int j = lane - 56;
-                        constexpr int LINE = 128 / (int)sizeof(T);
+                        const int j = lane - (64 - TLN);
                         const int xs = g.nx - 1 + V * j;
                         const int line_end = ((g.nx - 1) / LINE + 1) * LINE;
                         if (xs < line_end) {
@@ -876,6 +879,27 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
     // fp32 (four floats per lane, three coarse values per row) needs 180 VGPRs: held to 168 it spills 12 of them and runs
     // 5.5 ms per launch at 1025^3; at two waves per SIMD, unspilled, 4.8 ms. fp64 fits 163.
     const int minw = minw_env ? minw_env : (sizeof(T) == 4 ? 2 : 3);
+    // fp32: two floats per lane (rows of 2 * tpr lanes) up to 256-lane rows: 92 instead of 180 VGPRs, 0.590 against 0.618 ms per
+    // launch at 513^3; at 1025^3 the row would be a 512-thread workgroup (eight waves on one barrier per plane) and the four-float
+    // kernel at two waves per SIMD wins, 5.12 against 5.49 ms (MG_J2C_V2=0: four floats per lane everywhere)
+    static const bool v2_env = [] { const char *e = getenv("MG_J2C_V2"); return !(e && e[0] == '0'); }();
+    if constexpr (sizeof(T) == 4) {
+        if (v2_env && 2 * tpr <= 256) {
+            const int nby2 = (g.ny + 1) / 2, nbz2 = j2_nbz(g, 2 * tpr, 2);
+            const int grid2 = (((dup > 0 ? 2 : 1) * nby2 * nbz2 + 7) / 8) * 8;
+#define MG_J2C2(TPR2) \
+            do { \
+                if (damped) hipLaunchKernelGGL((k_jacobi2<T, TPR2, true, true, true, false, false, 2, 3, 2>), dim3(grid2), dim3(TPR2), 0, s, g, c, omega, u, rhs, out, nby2, nbz2, coarse, gc, dup); \
+                else hipLaunchKernelGGL((k_jacobi2<T, TPR2, false, true, true, false, false, 2, 3, 2>), dim3(grid2), dim3(TPR2), 0, s, g, c, omega, u, rhs, out, nby2, nbz2, coarse, gc, dup); \
+            } while (0)
+            switch (2 * tpr) {
+            case 256: MG_J2C2(256); return;
+            case 128: MG_J2C2(128); return;
+            default: break;
+            }
+#undef MG_J2C2
+        }
+    }
 #define MG_J2C(TPR) \
     do { \
         if (minw == 2) { \
