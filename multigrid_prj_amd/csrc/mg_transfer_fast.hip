@@ -450,7 +450,10 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
     const int nbz = (gc.nz + zcc - 1) / zcc;
     if (gc.nz != 1) dup_kc = 0;
     const int nblocks = nby * nbz, grid = (((dup_kc > 0 ? 2 : 1) * nblocks + 7) / 8) * 8;
-    const bool nt = (size_t)gf.nz * gf.plane * sizeof(T) >= ((size_t)64 << 20);
+    // rhs with ordinary loads: the odd fine row between two coarse rows is read by two workgroups, and a non-temporal first read
+    // made the second one miss (0.537 -> 0.519 ms at 513^3, three alternating runs each; MG_RR_NT=1 restores the streaming loads)
+    static const bool nt_env = [] { const char *e = getenv("MG_RR_NT"); return e && e[0] == '1'; }();
+    const bool nt = nt_env && (size_t)gf.nz * gf.plane * sizeof(T) >= ((size_t)64 << 20);
     const dim3 bl(64 * nw);
 #define MG_RR(NT, SEMI) \
     hipLaunchKernelGGL((k_resid_restrict_fw<T, NT, CR, SEMI>), dim3(grid), bl, 0, s, gf, gc, c, u, rhs, coarse, nby, nbz, zcc, dup_kc, dup_nzf)
