@@ -67,6 +67,10 @@ def parse(argv=None):
     ap.add_argument("--dry-rank", type=int, default=-1,
                     help="MEASUREMENT TOOL, one process, one GPU: run rank R of --gpus N with no peers (every exchange is a "
                          "no-op, results meaningless) to time that rank's compute schedule; the line is marked dry_run")
+    ap.add_argument("--rccl-same-gpu", action="store_true",
+                    help="REHEARSAL on a one-GPU box: every rank uses GPU 0 and tells RCCL it sits on a host of its own (NCCL_HOSTID), "
+                         "so that RCCL accepts two ranks on one device and carries the messages over its socket transport on the "
+                         "loopback interface -- the real RcclComm code path with N real ranks; the numbers mean nothing")
     ap.add_argument("--dist-min-n", type=int, default=0, help="mg_desc.dist_min_n (0 = library default)")
     ap.add_argument("--aniso-y", type=float, default=1.0, help="y-coupling multiplier of -(dxx + a dyy + dzz)")
     ap.add_argument("--aniso-x", type=float, default=1.0, help="x-coupling multiplier of -(a dxx + dyy + dzz)")
@@ -95,6 +99,9 @@ def launch(a, argv):
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if a.rccl_same_gpu:
+            env.update(NCCL_HOSTID=f"mg-rehearsal-rank{r}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_P2P_DISABLE="1",
+                       NCCL_SHM_DISABLE="1")
         # rank 0's stdout carries the JSON line; everything else goes to our stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=(r == 0)))
@@ -236,6 +243,8 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         if a.transport == "rccl":
+            if a.rccl_same_gpu:
+                device = local_rank = 0
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             ids = [capi.comm_unique_id() if rank == 0 else None]
@@ -367,7 +376,7 @@ def main():
                                f"{f'x-coupling x{a.aniso_x}, ' if a.aniso_x != 1.0 else ''}"
                                + (f"20 coarse sweeps, {a.dtype}" if a.semi else
                                   f"coarse {((a.n - 1) >> (a.levels - 1)) + 1}^3 iterated to rel. residual 0.1, {a.dtype}"),
-                   "parallelism": (f"z-slab x{world}" + ("" if a.transport == "rccl" else " (gloo rehearsal)")) if world > 1 else "single GPU",
+                   "parallelism": (f"z-slab x{world}" + ("" if a.transport == "rccl" else " (gloo rehearsal)") + (" (RCCL rehearsal: all ranks on GPU 0, socket transport)" if a.rccl_same_gpu else "")) if world > 1 else "single GPU",
                    "first_gathered_level": first_gathered},
         **({"dry_run": f"rank {rank} of {world} WITHOUT communication: one rank's compute schedule, not a result"} if dry else {}),
         "transport": transport_name, "rccl_ranks": transport_ranks if transport_name == "rccl" else None,

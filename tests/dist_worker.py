@@ -8,6 +8,11 @@ mode "model": CPU only. A numpy model of the slab-decomposed V-cycle -- the part
   reproduce the single-rank oracle bit for bit.
 mode "hip": the real distributed solver of libmg_hip (mg_create_distributed_hostcomm) with
   its exchanges carried by gloo, all ranks sharing GPU 0.
+mode "rccl": the PRODUCT transport. mg_create_distributed with an RCCL communicator of `world` ranks that all sit on
+  GPU 0: the test runner gives every rank its own NCCL_HOSTID, so RCCL takes them for ranks on different hosts, accepts
+  the shared device and moves the messages over its socket transport on the loopback interface. Everything above the
+  wire is the code an 8-GPU node runs: grouped ncclSend/ncclRecv on the main and the communication stream, the
+  all-gather of the coarse right-hand side, ncclAllReduce of the norms.
 Rank r writes its slab of the solution and its residual history to <outdir>/rank<r>.npz.
 """
 import json
@@ -33,9 +38,15 @@ def main():
     z0, nz, fg = capi.plan_slab(desc, world, rank, 0)
     b = np.load(case["rhs"])[z0:z0 + nz]
     cycles = case["cycles"]
-    if mode == "hip":
-        from multigrid_prj_amd.dist import torch_host_comm
-        s = capi.Solver(desc, device=0, rank=rank, nranks=world, host_comm=torch_host_comm())
+    if mode in ("hip", "rccl"):
+        if mode == "rccl":
+            ids = [capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)      # over gloo: the 128 bytes of the RCCL unique id
+            s = capi.Solver(desc, device=0, rank=rank, nranks=world, comm_id=ids[0])
+            assert s.comm_info()[2:] == (world, "rccl"), s.comm_info()
+        else:
+            from multigrid_prj_amd.dist import torch_host_comm
+            s = capi.Solver(desc, device=0, rank=rank, nranks=world, host_comm=torch_host_comm())
         s.set_rhs(b)
         s.cycle()                      # the first cycle also sends the right-hand side's ghost planes once
         g0, b0 = s.comm_stats()

@@ -28,11 +28,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _rank_env(mode, r, extra_env):
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    if mode == "rccl":
+        # RCCL refuses two ranks of one host on one device; ranks that claim hosts of their own are accepted and talk over
+        # the socket transport (loopback): the product's RcclComm with real peers on a one-GPU box
+        env.update(NCCL_HOSTID=f"mg-test-rank{r}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_P2P_DISABLE="1",
+                   NCCL_SHM_DISABLE="1")
+    return env
+
+
 def _run_ranks(mode, world, case, tmp_path, timeout=600, extra_env=None):
     port = str(_free_port())
-    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(r), str(world),
-                               port, json.dumps(case), str(tmp_path)], env=env, cwd=ROOT,
+                               port, json.dumps(case), str(tmp_path)], env=_rank_env(mode, r, extra_env), cwd=ROOT,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     try:
@@ -283,6 +292,35 @@ def test_hip_distributed_public_smooth_leaves_e_alone(rb, tmp_path):
         s.solve(0.0, 2)   # the worker's history run: two more cycles
         s.smooth(0, desc["smoother"], 2, capi.ARR_U, capi.ARR_RHS)
         assert np.array_equal(u, s.get_solution())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,levels,dtype,rb", [(2, 257, 5, 0, False), (3, 257, 5, 0, False), (2, 129, 4, 1, False), (2, 257, 5, 0, True)])
+def test_rccl_transport_carries_the_distributed_cycle(world, n, levels, dtype, rb, tmp_path):
+    """The PRODUCT transport with real peers: `world` ranks, one RCCL communicator, grouped ncclSend/ncclRecv on the solver's
+    main and communication streams (overlapped interior / boundary pieces, early exchange, halo reuse, prolongation fold on
+    slabs), the all-gather of the coarse right-hand side and ncclAllReduce of the norms -- all ranks on the box's one GPU, each
+    claiming a host of its own so that RCCL accepts them (socket transport on loopback; see tests/dist_worker.py). The result
+    must be the single-GPU solver's and the oracle's, bit for bit, and the histories must agree on every rank."""
+    from multigrid_prj_amd import capi
+    case, desc, b = _case(tmp_path, n, levels, 1, cycles=3, dtype=dtype, rb=rb)
+    desc["dist_min_n"] = 65
+    case["desc"] = desc
+    u, hists, fg = _run_ranks("rccl", world, case, tmp_path, timeout=900)
+    assert fg >= 2
+    with capi.Solver(capi.make_desc(**desc)) as s:
+        s.set_rhs(b)
+        for _ in range(case["cycles"]):
+            s.cycle()
+        h1, _ = s.solve(0.0, 2)
+        u1 = s.get_solution()
+    assert np.array_equal(u, u1)
+    u_ref, h_ref = _oracle(desc, b, case["cycles"])
+    assert np.array_equal(u, u_ref)
+    for h in hists:
+        np.testing.assert_allclose(h, h1, rtol=1e-12 if dtype == 0 else 1e-6)
+    if not rb and n >= 257:   # Jacobi V(2,2), rows wide enough for the fused slab kernels: the finest level's post-smoothing pair folded the prolongation in
+        assert all(int(p["fold_launches"]) == 2 and int(p["prolong_launches"]) == 0 for p in _run_ranks.last_parts)
 
 
 @pytest.mark.gpu
