@@ -55,3 +55,19 @@ def test_bench_dry_rank_runs_one_ranks_schedule_on_one_gpu():
     assert "dry_run" in out and "WITHOUT communication" in out["dry_run"]
     assert out["transport"] == "dry-run" and out["rccl_ranks"] is None and out["n_gpus"] == 4
     assert out["comm_per_cycle"]["message_groups"] > 0 and out["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_launches_real_rccl_ranks_on_one_gpu():
+    """`python3 bench.py --gpus 2` as the driver types it, with RCCL as the transport: --rccl-same-gpu puts both ranks on GPU 0
+    and gives each a host id of its own, so RCCL accepts them and moves the halos over its socket transport. The line must come
+    from two RCCL ranks and show the cycle converging like the single-GPU one."""
+    p = _run(["--gpus", "2", "--rccl-same-gpu", "--steps", "3", "--warmup", "1", "--grid", "257", "--levels", "5", "--no-cpu-baseline",
+              "--launch-timeout", "240"], timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["transport"] == "rccl" and out["rccl_ranks"] == 2 and out["n_gpus"] == 2
+    assert len(out["ms_per_step_ranks"]) == 2 and out["comm_per_cycle"]["message_groups"] > 0
+    assert 0.15 < out["residual_drop_per_cycle"] < 0.30      # 0.226 on one GPU
