@@ -239,6 +239,9 @@ def main():
     host_comm = None
     device = local_rank
     if world > 1 and not dry:
+        if a.rccl_same_gpu:   # also under torch.distributed.run, where nobody prepared the rank's environment
+            os.environ.update(NCCL_HOSTID=f"mg-rehearsal-rank{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
+                              NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1")
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
