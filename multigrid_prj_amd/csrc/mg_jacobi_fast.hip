@@ -770,6 +770,7 @@ template <typename T>
 void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out, bool zero_u, int dup)
 {
     constexpr int V = VecOf<T>::V;
+    if (pair_wide_ok<T>(g)) { launch_pair_wide<T>(s, g, Geom{}, c, omega, u, (const T *)nullptr, rhs, out, zero_u, false, dup); return; }
     const int tpr = (g.nx - 1) / V;
     const int ncopy = dup > 0 ? 2 : 1;   // dup: the same geometry once more, `dup` planes further up, in the same launch
     // three output rows per workgroup where the correction is not folded in: 5 instead of 4 first-sweep rows
@@ -818,9 +819,10 @@ void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
                      const T *coarse, const Geom &gc, int dup)
 {
     constexpr int V = VecOf<T>::V;
+    if (coarse) dup = 0;   // the folding variant only runs on whole levels
+    if (pair_wide_ok<T>(g)) { launch_pair_wide<T>(s, g, gc, c, (T)1, u, coarse, rhs, out, false, true, dup); return; }
     const int tpr = (g.nx - 1) / V;
     const int ncopy = (dup > 0 && !coarse) ? 2 : 1;
-    if (coarse) dup = 0;   // the folding variant only runs on whole levels
     static const int tyo_env = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
     const int tyo = j2_tyo_for(tpr, tyo_env);
     const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g, tpr, (tyo == 3 && !coarse) ? 3 : 2);
@@ -871,6 +873,7 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
                          const T *coarse, const T *rhs, T *out, int dup)
 {
     constexpr int V = VecOf<T>::V;
+    if (pair_wide_ok<T>(g)) { launch_pair_wide<T>(s, g, gc, c, omega, u, coarse, rhs, out, false, false, dup); return; }
     const int tpr = (g.nx - 1) / V;
     const int nby = (g.ny + J2_TYO - 1) / J2_TYO, nbz = j2_nbz(g, tpr, 2);
     const int nblocks = nby * nbz, grid = (((dup > 0 ? 2 : 1) * nblocks + 7) / 8) * 8;

@@ -38,6 +38,14 @@ void launch_jacobi2_corr(hipStream_t s, const Geom &g, const Geom &gc, const Coe
                          const T *coarse, const T *rhs, T *out, int dup_planes = 0);
 // on the pieces of a z-slab: g = the piece, gc = the WHOLE coarse slab, coarse = its local plane 0 (two valid ghost planes either side)
 template <typename T> bool jacobi2_corr_slab_ok(const Geom &gf, const Geom &gc);
+// wide-tile form of the same pairs (mg_pair_wide.hip): rows of 128 / 256 lanes on levels big enough to fill the chip with
+// 1024-thread workgroups; launch_jacobi2 / launch_jacobi2_corr / launch_rb_fused hand over to it when pair_wide_ok
+// coarse != nullptr: out = pair(u + P coarse); zero_u: u == 0; rb: one red-black sweep instead of two Jacobi sweeps
+template <typename T> bool pair_wide_ok(const Geom &g);
+void set_pair_wide(int mode);   // measurement tools only (tools/pairbench.hip): 0 = never, 1 = wherever the shape allows, -1 = default
+template <typename T>
+void launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u, const T *coarse,
+                      const T *rhs, T *out, bool zero_u, bool rb, int dup_planes);
 // zebra line Gauss-Seidel along y: one colour pass; cp_den = the 2*ny factors of zebra_line_factors(cy, cd, ny) (device)
 template <typename T>
 void launch_zebra_y(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u, const T *rhs, T *dp,

@@ -1,0 +1,449 @@
+// mg_pair_wide.hip -- the V-cycle's smoothing pairs on HBM-resident levels, wide-tile form (round 3), gfx950.
+//
+//     out = J(J(u))            pre-smoothing pair            (reference sweep: include/solvers.hpp:64-83, twice)
+//     out = J(J(u + P e))      post-smoothing pair with the prolongation (src/multigrid.cpp:3-27) folded in
+//     out = J(J(0))            pre-smoothing pair of a level that starts from the zero guess
+//
+// Why a second form of k_jacobi2 (mg_jacobi_fast.hip). That kernel keeps a workgroup's whole state in the registers of
+// ONE thread column: TYO + 2 rows of u per thread for TYO output rows, so the first sweep is evaluated on (TYO + 2) / TYO
+// = 1.67 x (plain) or 2 x (folding variant) the rows it owns and the coarse correction on 3 x; its run time followed
+// the count of fp64 instructions per output point (75, 67, 88 per point: 0.86, 0.79, 1.03 ms at 513^3), not the bytes it
+// moves -- at three waves per SIMD a wave issues one fp64 instruction per 8 cycles and the vector pipe idles whenever
+// fewer than two of the three are runnable.  Here a workgroup is a TILE of G groups x R = 2 rows: every thread owns two
+// rows (an even one and the odd one above it), G groups of row-wide wave teams are stacked in y, and neighbouring groups
+// exchange their rows through LDS instead of recomputing them:
+//   * first sweep on G*R rows for G*R - 2 output rows: 8 / 6 = 1.33 x at 513^3 fp64 (G = 4), 16 / 14 at 257^3 (G = 8);
+//   * the correction P e is evaluated once per owned row (the two tile-edge groups add one halo row each);
+//   * 10 persistent 16-byte registers per thread instead of 24-32: <= 128 VGPRs, four waves per SIMD; one workgroup of
+//     1024 threads per CU;
+//   * per plane step: u(p+1) (corrected) -> LDS slot A; first sweep on plane p reads its x/y neighbours from LDS slot
+//     B (u(p), published one step earlier) and the z neighbours from registers; v(p) -> LDS; second sweep on plane p-1
+//     reads v(p-1)'s x/y neighbours from LDS and v(p-2), v(p) from registers; ONE barrier per plane.
+// Per-point arithmetic, its order, -ffp-contract=off and the correctly rounded division are those of k_jacobi2 and of
+// two k_sweep3d launches: the output is bit-identical (tests/test_gpu_parity.py compares with the oracle).
+// Geometry conventions (z-slab pieces, ghost planes, the second copy `dup_planes` further up, coarse planes addressed by
+// global plane index) are exactly k_jacobi2's, so the launchers of mg_jacobi_fast.hip hand over to this kernel unchanged.
+// MFMA unused: a 7-point stencil is not a contraction; the kernel is bound by HBM traffic (24-25 B per point).
+#include "mg_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+namespace mg {
+namespace {
+
+template <typename T> struct WV;
+template <> struct WV<double> { static constexpr int V = 2; };
+template <> struct WV<float> { static constexpr int V = 4; };
+
+// RB: the pipeline runs red-black Gauss-Seidel instead of Jacobi (see k_jacobi2): phase 1 = red half-sweep (black
+// points copied), phase 2 = black half-sweep on the plane behind -- ONE red-black sweep per pass
+template <typename T, int TPR, int G, bool DAMPED, bool CORR, bool ZEROU, bool RB = false>
+__global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, const T *__restrict__ u_,
+                                                   const T *__restrict__ rhs_, T *__restrict__ out_, int nby, int nbz,
+                                                   const T *__restrict__ coarse, Geom gc, int dup_planes)
+{
+    constexpr int V = WV<T>::V, CV = V / 2, NR = CV + 1;
+    constexpr int R = 2, NROW = G * R, S = NROW - 2;
+    constexpr int LP = TPR * V + 2 * V;  // LDS row: V pad | TPR*V values | tail column | pad
+    typedef T vec __attribute__((ext_vector_type(V)));
+    static_assert(G >= 2 && (TPR % 64) == 0, "row-wide wave teams, at least two groups");
+    // u planes p (read) / p+1 (written): rows 1 .. NROW = the tile, row 0 / NROW+1 = the halo rows below / above it
+    __shared__ __align__(16) T su[ZEROU ? 1 : 2][ZEROU ? 1 : NROW + 2][ZEROU ? V : LP];
+    __shared__ __align__(16) T sv[2][NROW][LP];  // first-sweep planes p-1 (read) / p (written)
+
+    const int nblocks = nby * nbz, ntotal = dup_planes > 0 ? 2 * nblocks : nblocks;
+    const int per = (ntotal + 7) >> 3;
+    int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order
+    if (bid >= ntotal) return;                             // whole workgroup
+    const bool second = bid >= nblocks;
+    if (second) { bid -= nblocks; g.gz0 += dup_planes; }
+    const long long dup_off = second ? (long long)dup_planes * g.plane : 0;
+    const T *__restrict__ u = u_ + dup_off;
+    const T *__restrict__ rhs = rhs_ + dup_off;
+    T *__restrict__ out = out_ + dup_off;
+    const int by = bid % nby, bz = bid / nby;
+    const int t = threadIdx.x, lane = t & 63;
+    const int grp = __builtin_amdgcn_readfirstlane(t / TPR);  // y-group of this wave: scalar
+    const int xt = t - grp * TPR;                             // lane position in the row
+    const int x0 = V * xt;                                    // the gate guarantees nx - 1 == TPR * V
+    const bool tail = (xt == TPR - 1);                        // last thread of the row: also owns the Dirichlet column nx-1
+    const bool tailwave = (xt >> 6) == (TPR >> 6) - 1;
+    const int Y0 = by * S, i0 = grp * R;                      // tile rows Y0 .. Y0+NROW-1; this thread: tile rows i0, i0+1
+    const int ZC = (g.nz + nbz - 1) / nbz;
+    const int z0 = bz * ZC, z1 = min(z0 + ZC, g.nz);
+    const bool lo_grp = (grp == 0), hi_grp = (grp == G - 1);  // the groups that also fetch a halo row of u
+
+    long long urow[R];
+    bool ybnd[R], outrow[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int y = Y0 + i0 + r, yc = min(y, g.ny - 1);
+        ybnd[r] = (yc == 0) || (yc == g.ny - 1);
+        urow[r] = (long long)yc * g.pitch;
+        const int i = i0 + r;
+        // second-sweep (output) rows of this tile: its inner rows, and row 0 of the grid
+        outrow[r] = (i >= 1 || by == 0) && (i <= NROW - 2) && (y < g.ny);
+    }
+    const int hy = lo_grp ? max(Y0 - 1, 0) : min(Y0 + NROW, g.ny - 1);
+    const long long hrow = (long long)hy * g.pitch;
+    const int hs = lo_grp ? 0 : NROW + 1;  // its LDS row
+
+    const int zhalo = (g.gnz != g.nz) ? 2 : 1;
+    const int gzo = g.gz0, gzn = g.gnz;
+    auto plane_of = [&](int p) { return (long long)min(max(p, -zhalo), g.nz - 1 + zhalo) * g.plane; };
+
+    // ---- on-the-fly prolongation (CORR): coarse rows A = (Y0+i0)/2 under the even row, B = A+1; the odd row is their
+    // mean. Tile-edge groups: the halo row below the tile is odd (mean of A-1 and A), the one above it even (= B).
+    const T hf = (T)0.5;
+    typedef T cwide __attribute__((ext_vector_type(NR <= 2 ? 2 : 4), aligned(CV * sizeof(T))));
+    int crow[3] = {0, 0, 0};  // offsets of coarse rows A-1, A, B (clamped into the grid): workgroup-uniform per wave
+    const int ic0 = CV * xt;
+    if (CORR) {
+        const int A = (Y0 + i0) >> 1;
+        crow[0] = min(max(A - 1, 0), gc.ny - 1) * gc.pitch;
+        crow[1] = min(A, gc.ny - 1) * gc.pitch;
+        crow[2] = min(A + 1, gc.ny - 1) * gc.pitch;
+    }
+    auto cplane = [&](int P, int up1) {
+        const int kc = ((gzo + P + up1) >> 1) - gc.gz0;
+        return coarse + (long long)min(max(kc, -zhalo), gc.nz - 1 + zhalo) * gc.plane;
+    };
+    auto load_crow = [&](const T *base, int j, T (&d)[NR]) {
+        const cwide w = *(const cwide *)((base + crow[j]) + ic0);
+#pragma unroll
+        for (int m = 0; m < NR; m++) d[m] = w[m];
+    };
+    // raw coarse values under fine plane P: Ra = lower (or only) coarse plane, Rb = the upper one of an odd plane
+    auto raw = [&](int P, T (&Ra)[3][NR], T (&Rb)[3][NR]) {
+        const T *c0 = cplane(P, 0);
+        const bool odd = ((gzo + P) & 1) != 0;
+        const T *c1 = cplane(P, 1);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (j == 0 && !lo_grp) {
+#pragma unroll
+                for (int m = 0; m < NR; m++) { Ra[j][m] = 0; Rb[j][m] = 0; }
+                continue;
+            }
+            load_crow(c0, j, Ra[j]);
+            if (odd) load_crow(c1, j, Rb[j]);
+            else {
+#pragma unroll
+                for (int m = 0; m < NR; m++) Rb[j][m] = 0;
+            }
+        }
+    };
+    // z phase: correction rows interpolated onto fine plane P (zero outside the grid)
+    auto zfin = [&](int P, const T (&Ra)[3][NR], const T (&Rb)[3][NR], T (&Z)[3][NR]) {
+        const int gP = gzo + P;
+        const bool in = (gP >= 0) && (gP < gzn), odd = (gP & 1) != 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+#pragma unroll
+            for (int m = 0; m < NR; m++) {
+                const T z = odd ? hf * (Ra[j][m] + Rb[j][m]) : Ra[j][m];
+                Z[j][m] = in ? z : (T)0;
+            }
+        }
+    };
+    // x phase on a y-interpolated row: own vector / the tail column
+    auto pe_vec = [&](const T (&Yr)[NR]) {
+        vec w;
+#pragma unroll
+        for (int mm = 0; mm < CV; mm++) {
+            w[2 * mm] = Yr[mm];
+            w[2 * mm + 1] = hf * (Yr[mm] + Yr[mm + 1]);
+        }
+        return w;
+    };
+    auto add_vec = [&](vec a, vec w) {
+        vec o;
+#pragma unroll
+        for (int e = 0; e < V; e++) o[e] = a[e] + w[e];
+        return o;
+    };
+    // u + P e on the thread's two rows (w), their tail-column values (tl) and, tile-edge groups, the halo row (h, htl)
+    auto correct = [&](const T (&Z)[3][NR], vec (&w)[R], T (&tl)[R], vec &h, T &htl, bool with_halo) {
+        T Yodd[NR];
+#pragma unroll
+        for (int m = 0; m < NR; m++) Yodd[m] = hf * (Z[1][m] + Z[2][m]);
+        w[0] = add_vec(w[0], pe_vec(Z[1]));
+        w[1] = add_vec(w[1], pe_vec(Yodd));
+        tl[0] = tl[0] + Z[1][CV];
+        tl[1] = tl[1] + Yodd[CV];
+        if (with_halo) {
+            if (lo_grp) {
+                T Yh[NR];
+#pragma unroll
+                for (int m = 0; m < NR; m++) Yh[m] = hf * (Z[0][m] + Z[1][m]);
+                h = add_vec(h, pe_vec(Yh));
+                htl = htl + Yh[CV];
+            } else if (hi_grp) {
+                h = add_vec(h, pe_vec(Z[2]));
+                htl = htl + Z[2][CV];
+            }
+        }
+    };
+
+    // one point-Jacobi / Gauss-Seidel-colour update of a vector: neighbours in z (zm, zp), y (ym, yp), x (xm, xp)
+    auto update = [&](const vec &zm, const vec &cc, const vec &zp, const vec &ym, const vec &yp, T xm, T xp,
+                      const vec &bb, bool rb) {
+        T num[V], quo[V];
+        vec res;
+#pragma unroll
+        for (int e = 0; e < V; e++) {
+            const T left = (e == 0) ? xm : cc[e > 0 ? e - 1 : 0];
+            const T right = (e == V - 1) ? xp : cc[e < V - 1 ? e + 1 : 0];
+            T sum = 0;
+            sum += c.cz * zm[e];
+            sum += c.cy * ym[e];
+            sum += c.cx * left;
+            sum += c.cx * right;
+            sum += c.cy * yp[e];
+            sum += c.cz * zp[e];
+            num[e] = bb[e] - sum;
+        }
+        div_cd_n<T, V>(num, quo, c);
+#pragma unroll
+        for (int e = 0; e < V; e++) {
+            T jac = quo[e];
+            if (DAMPED) jac = cc[e] + omega * (jac - cc[e]);
+            res[e] = (rb || (x0 + e == 0)) ? bb[e] : jac;
+        }
+        return res;
+    };
+
+    vec um[R], uc[R], up[R], vm[R], vc[R], bq[R];
+    // ---- prologue: planes z0-2 and z0-1 of u (corrected), plane z0-1 published
+    {
+        T ter[R];
+        vec hh = (vec)(0);
+        T hter = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            um[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (plane_of(z0 - 2) + urow[r])) + x0);
+            uc[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (plane_of(z0 - 1) + urow[r])) + x0);
+            ter[r] = 0;
+            if (tail && !ZEROU) ter[r] = (u + (plane_of(z0 - 1) + urow[r]))[x0 + V];
+        }
+        if (!ZEROU && (lo_grp || hi_grp)) {
+            hh = *(const vec *)((u + (plane_of(z0 - 1) + hrow)) + x0);
+            if (tail) hter = (u + (plane_of(z0 - 1) + hrow))[x0 + V];
+        }
+        if (CORR) {
+            T Ra[3][NR], Rb[3][NR], Z[3][NR];
+            T dummy_t[R] = {0, 0};
+            vec dummy_h = (vec)(0);
+            T dummy_ht = 0;
+            raw(z0 - 2, Ra, Rb); zfin(z0 - 2, Ra, Rb, Z);
+            correct(Z, um, dummy_t, dummy_h, dummy_ht, false);
+            raw(z0 - 1, Ra, Rb); zfin(z0 - 1, Ra, Rb, Z);
+            correct(Z, uc, ter, hh, hter, true);
+        }
+        if constexpr (!ZEROU) {
+            const int sl = (z0 - 1) & 1;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                *(vec *)&su[sl][1 + i0 + r][V + x0] = uc[r];
+                if (tail) su[sl][1 + i0 + r][V + x0 + V] = ter[r];
+                if (xt == 0) { su[0][1 + i0 + r][V - 1] = 0; su[1][1 + i0 + r][V - 1] = 0; }
+            }
+            if (lo_grp || hi_grp) {
+                *(vec *)&su[sl][hs][V + x0] = hh;
+                if (tail) su[sl][hs][V + x0 + V] = hter;
+                if (xt == 0) { su[0][hs][V - 1] = 0; su[1][hs][V - 1] = 0; }
+            }
+        }
+        if (xt == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) { sv[0][i0 + r][V - 1] = 0; sv[1][i0 + r][V - 1] = 0; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) { vm[r] = (vec)(0); vc[r] = (vec)(0); bq[r] = (vec)(0); }
+
+    for (int p = z0 - 1; p <= z1; p++) {
+        const long long po = plane_of(p), pn = plane_of(p + 1);
+        // ---- every load of this step first
+        vec b[R], hn = (vec)(0);
+        T vtail[R], ter_n[R], hter_n = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            up[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (pn + urow[r])) + x0);
+            ter_n[r] = 0;
+            if (tail && !ZEROU) ter_n[r] = (u + (pn + urow[r]))[x0 + V];
+        }
+        if (!ZEROU && (lo_grp || hi_grp)) {
+            hn = *(const vec *)((u + (pn + hrow)) + x0);
+            if (tail) hter_n = (u + (pn + hrow))[x0 + V];
+        }
+        T Ra[3][NR], Rb[3][NR];
+        if (CORR) raw(p + 1, Ra, Rb);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            b[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
+            vtail[r] = 0;
+            if (tail) vtail[r] = (rhs + (po + urow[r]))[x0 + V];  // first sweep on the Dirichlet column: v = rhs
+        }
+        // ---- u(p+1) + P e -> LDS slot (p+1)&1 (read by the next step's first sweep)
+        if (CORR) {
+            T Z[3][NR];
+            zfin(p + 1, Ra, Rb, Z);
+            correct(Z, up, ter_n, hn, hter_n, true);
+        }
+        if constexpr (!ZEROU) {
+            const int sn = (p + 1) & 1;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                *(vec *)&su[sn][1 + i0 + r][V + x0] = up[r];
+                if (tail) su[sn][1 + i0 + r][V + x0 + V] = ter_n[r];
+            }
+            if (lo_grp || hi_grp) {
+                *(vec *)&su[sn][hs][V + x0] = hn;
+                if (tail) su[sn][hs][V + x0 + V] = hter_n;
+            }
+        }
+        // ---- first sweep on plane p, both rows
+        vec v[R];
+        {
+            const int sc = p & 1;
+            const bool zbp = (gzo + p == 0) || (gzo + p == gzn - 1);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                T xm = 0, xp = 0;
+                vec yo = (vec)(0);  // the y-neighbour that is not this thread's other row
+                if constexpr (!ZEROU) {
+                    xm = su[sc][1 + i0 + r][V + x0 - 1];
+                    xp = su[sc][1 + i0 + r][V + x0 + V];
+                    yo = *(const vec *)&su[sc][(r == 0) ? i0 : i0 + 3][V + x0];
+                }
+                const vec ym = (r == 0) ? yo : uc[0];
+                const vec yp = (r == 0) ? uc[1] : yo;
+                v[r] = update(um[r], uc[r], up[r], ym, yp, xm, xp, b[r], zbp || ybnd[r]);
+                if (RB) {
+#pragma unroll
+                    for (int e = 0; e < V; e++)
+                        if (((x0 + e + Y0 + i0 + r + gzo + p) & 1) != 0) v[r][e] = uc[r][e];  // not red: unchanged
+                }
+                *(vec *)&sv[sc][i0 + r][V + x0] = v[r];
+                if (tail) sv[sc][i0 + r][V + x0 + V] = vtail[r];
+            }
+        }
+        // ---- second sweep on plane q = p-1, output rows
+        const int q = p - 1;
+        if (q >= z0 && q < z1) {
+            const bool zbq = (gzo + q == 0) || (gzo + q == gzn - 1);
+            const int sl = q & 1;
+            const long long qo = (long long)q * g.plane;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (outrow[r]) {
+                    const int i = i0 + r;
+                    const T xm = sv[sl][i][V + x0 - 1], xp = sv[sl][i][V + x0 + V];
+                    const vec yo = *(const vec *)&sv[sl][(r == 0) ? max(i - 1, 0) : i + 1][V + x0];
+                    const vec ym = (r == 0) ? yo : vc[0];
+                    const vec yp = (r == 0) ? vc[1] : yo;
+                    vec res = update(vm[r], vc[r], v[r], ym, yp, xm, xp, bq[r], zbq || ybnd[r]);
+                    if (RB) {
+#pragma unroll
+                        for (int e = 0; e < V; e++)
+                            if (((x0 + e + Y0 + i + gzo + q) & 1) == 0) res[e] = vc[r][e];  // not black: unchanged
+                    }
+                    __builtin_nontemporal_store(res, (vec *)((out + (qo + urow[r])) + x0));
+                    constexpr int LINE = 128 / (int)sizeof(T), TLN = LINE / V;  // lanes that write the tail line
+                    if (tailwave && lane >= 64 - TLN) {
+                        // column nx-1 (Dirichlet) as one full 128-byte line: value + zero padding
+                        const int j = lane - (64 - TLN);
+                        const int xs = g.nx - 1 + V * j;
+                        const int line_end = ((g.nx - 1) / LINE + 1) * LINE;
+                        if (xs < line_end) {
+                            const long long rb0 = qo + urow[r];
+                            vec tv = (vec)(0);
+                            if (j == 0) tv[0] = rhs[rb0 + g.nx - 1];
+                            __builtin_nontemporal_store(tv, (vec *)(out + rb0 + xs));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; r++) { um[r] = uc[r]; uc[r] = up[r]; vm[r] = vc[r]; vc[r] = v[r]; bq[r] = b[r]; }
+    }
+}
+
+// z-chunks per launch: one workgroup per CU, so the launch runs in rounds of 256 workgroups; a chunk of zc planes costs
+// zc + 2 plane steps (+ the prologue). Pick the chunk count whose last round is as full as possible.
+static int wide_nbz(const Geom &g, int nby, int ncopy)
+{
+    static const int zc_env = [] { const char *e = getenv("MG_PW_ZC"); return e ? atoi(e) : 0; }();
+    if (zc_env > 1) return (g.nz + zc_env - 1) / zc_env;
+    int bestk = 1;
+    double best = 1e30;
+    for (int k = 1; k <= std::max(1, g.nz / 4); k++) {
+        const int zc = (g.nz + k - 1) / k;
+        const int kk = (g.nz + zc - 1) / zc;  // chunks actually launched
+        const double rounds = std::ceil((double)ncopy * nby * kk / 256.0);
+        const double cost = std::max(rounds, 1.0) * (zc + 3.5);
+        if (cost < best - 1e-9) { best = cost; bestk = kk; }
+    }
+    return bestk;
+}
+
+int g_wide_mode = -1;
+
+}  // namespace
+
+void set_pair_wide(int mode) { g_wide_mode = mode; }
+
+// wide tiles need whole rows of 128 or 256 lanes (n = 257, 513 in fp64; 513, 1025 in fp32) and enough rows and planes
+// to fill 256 CUs with 1024-thread workgroups; everything else stays with k_jacobi2
+template <typename T>
+bool pair_wide_ok(const Geom &g)
+{
+    constexpr int V = WV<T>::V;
+    static const bool enabled = [] { const char *e = getenv("MG_PAIR_WIDE"); return !(e && e[0] == '0'); }();
+    if (g_wide_mode == 0 || (g_wide_mode < 0 && !enabled) || g.dim != 3 || (g.nx - 1) % V != 0) return false;
+    const int tpr = (g.nx - 1) / V;
+    if (tpr != 128 && tpr != 256) return false;
+    static const int min_rows = [] { const char *e = getenv("MG_PW_MIN_NY"); return e ? atoi(e) : 200; }();
+    return g.ny >= min_rows && g.nz >= 2;
+}
+
+template <typename T>
+void launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u, const T *coarse,
+                      const T *rhs, T *out, bool zero_u, bool rb, int dup)
+{
+    constexpr int V = WV<T>::V;
+    const int tpr = (g.nx - 1) / V;
+    const int G = 1024 / tpr, S = 2 * G - 2;
+    const int nby = (g.ny - 1 + S - 1) / S;
+    const int ncopy = dup > 0 ? 2 : 1;
+    const int nbz = wide_nbz(g, nby, ncopy);
+    const int grid = ((ncopy * nby * nbz + 7) / 8) * 8;
+    const bool damped = (omega != (T)1) && !rb;
+#define MG_PW(TPR, GG, D, C, Z, RBB) \
+    hipLaunchKernelGGL((k_pairw<T, TPR, GG, D, C, Z, RBB>), dim3(grid), dim3(TPR * GG), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, dup)
+#define MG_PW_SHAPE(TPR, GG) \
+    do { \
+        if (rb) { if (coarse) MG_PW(TPR, GG, false, true, false, true); else MG_PW(TPR, GG, false, false, false, true); } \
+        else if (coarse) { if (damped) MG_PW(TPR, GG, true, true, false, false); else MG_PW(TPR, GG, false, true, false, false); } \
+        else if (zero_u) { if (damped) MG_PW(TPR, GG, true, false, true, false); else MG_PW(TPR, GG, false, false, true, false); } \
+        else { if (damped) MG_PW(TPR, GG, true, false, false, false); else MG_PW(TPR, GG, false, false, false, false); } \
+    } while (0)
+    (void)G;
+    if (tpr == 256) MG_PW_SHAPE(256, 4);
+    else MG_PW_SHAPE(128, 8);
+#undef MG_PW_SHAPE
+#undef MG_PW
+}
+
+template bool pair_wide_ok<double>(const Geom &);
+template bool pair_wide_ok<float>(const Geom &);
+template void launch_pair_wide<double>(hipStream_t, const Geom &, const Geom &, const Coef<double> &, double, const double *, const double *, const double *, double *, bool, bool, int);
+template void launch_pair_wide<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, float, const float *, const float *, const float *, float *, bool, bool, int);
+
+}  // namespace mg
