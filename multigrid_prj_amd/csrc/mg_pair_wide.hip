@@ -265,34 +265,49 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
 #pragma unroll
     for (int r = 0; r < R; r++) { vm[r] = (vec)(0); vc[r] = (vec)(0); bq[r] = (vec)(0); }
 
-    for (int p = z0 - 1; p <= z1; p++) {
-        const long long po = plane_of(p), pn = plane_of(p + 1);
-        // ---- every load of this step first
-        vec b[R], hn = (vec)(0);
-        T vtail[R], ter_n[R], hter_n = 0;
+    // Software prefetch, one plane step ahead: the u rows of plane p+2 and the rhs rows of plane p+1 are requested at the top
+    // of step p and consumed at the top of step p+1, so a step's HBM latency runs under the arithmetic of the step before
+    // (all 16 waves of the tile meet at one barrier per plane: without it the CU alternates between waiting and computing).
+    vec nu[R], nb[R], nh = (vec)(0);
+    T nter[R], nvt[R], nhter = 0;
+    auto fetch = [&](int pu1, int pb) {   // raw u of plane pu1 (rows, halo row, tail column) and rhs of plane pb
+        const long long pn = plane_of(pu1), po = plane_of(pb);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            up[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (pn + urow[r])) + x0);
-            ter_n[r] = 0;
-            if (tail && !ZEROU) ter_n[r] = (u + (pn + urow[r]))[x0 + V];
+            nu[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (pn + urow[r])) + x0);
+            nter[r] = 0;
+            if (tail && !ZEROU) nter[r] = (u + (pn + urow[r]))[x0 + V];
         }
         if (!ZEROU && (lo_grp || hi_grp)) {
-            hn = *(const vec *)((u + (pn + hrow)) + x0);
-            if (tail) hter_n = (u + (pn + hrow))[x0 + V];
+            nh = *(const vec *)((u + (pn + hrow)) + x0);
+            if (tail) nhter = (u + (pn + hrow))[x0 + V];
         }
-        T Ra[3][NR], Rb[3][NR];
-        if (CORR) raw(p + 1, Ra, Rb);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            b[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
-            vtail[r] = 0;
-            if (tail) vtail[r] = (rhs + (po + urow[r]))[x0 + V];  // first sweep on the Dirichlet column: v = rhs
+            nb[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
+            nvt[r] = 0;
+            if (tail) nvt[r] = (rhs + (po + urow[r]))[x0 + V];  // first sweep on the Dirichlet column: v = rhs
         }
+    };
+    fetch(z0, z0 - 1);
+
+    for (int p = z0 - 1; p <= z1; p++) {
+        // ---- this step's operands were requested one step ago; the next step's are requested now
+        vec b[R], hn = nh;
+        T vtail[R], ter_n[R], hter_n = nhter;
+#pragma unroll
+        for (int r = 0; r < R; r++) { up[r] = nu[r]; b[r] = nb[r]; ter_n[r] = nter[r]; vtail[r] = nvt[r]; }
+        T Ra[3][NR], Rb[3][NR];
+        if (CORR) raw(p + 1, Ra, Rb);
+        else fetch(p + 2, p + 1);
         // ---- u(p+1) + P e -> LDS slot (p+1)&1 (read by the next step's first sweep)
         if (CORR) {
             T Z[3][NR];
             zfin(p + 1, Ra, Rb, Z);
             correct(Z, up, ter_n, hn, hter_n, true);
+            // (the folding variant requests the next step's operands only now: the coarse values and the z / y / x phases
+            // above would not fit beside them in 128 registers; the coarse loads are cache hits, the delay is short)
+            fetch(p + 2, p + 1);
         }
         if constexpr (!ZEROU) {
             const int sn = (p + 1) & 1;
