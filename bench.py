@@ -310,11 +310,17 @@ def main():
 
     # mg_solve's cycle = this cycle + one finest-grid residual norm: time a few of them for the record
     barrier()
-    s.zero_array(capi.ARR_U, 0)
-    ts0 = time.perf_counter()
-    s.solve(0.0, 6)
-    barrier()
-    solve_ms_per_cycle = 1e3 * (time.perf_counter() - ts0) / 6
+    # (marginal cost of one more iteration of mg_solve's loop: the loop's fixed part -- sum b^2, the first norm and, where the
+    # norm rides on the next cycle's first pair, the one speculative pair that is dropped at the end -- is not a per-cycle cost)
+    def timed_solve(k):
+        s.zero_array(capi.ARR_U, 0)
+        barrier()
+        t0 = time.perf_counter()
+        s.solve(0.0, k)
+        barrier()
+        return time.perf_counter() - t0
+    timed_solve(2)
+    solve_ms_per_cycle = 1e3 * (timed_solve(14) - timed_solve(4)) / 10
 
     # single streaming sweeps of the finest grid (the unfused kernel the fused pair replaces)
     stream_ms = None

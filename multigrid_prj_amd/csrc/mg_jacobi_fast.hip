@@ -767,10 +767,11 @@ bool jacobi2_slab_ok(const Geom &g)
 }
 
 template <typename T>
-void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out, bool zero_u, int dup)
+int launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out, bool zero_u, int dup,
+                   double *d_partials)
 {
     constexpr int V = VecOf<T>::V;
-    if (pair_wide_ok<T>(g)) { launch_pair_wide<T>(s, g, Geom{}, c, omega, u, (const T *)nullptr, rhs, out, zero_u, false, dup); return; }
+    if (pair_wide_ok<T>(g)) return launch_pair_wide<T>(s, g, Geom{}, c, omega, u, (const T *)nullptr, rhs, out, zero_u, false, dup, d_partials);
     const int tpr = (g.nx - 1) / V;
     const int ncopy = dup > 0 ? 2 : 1;   // dup: the same geometry once more, `dup` planes further up, in the same launch
     // three output rows per workgroup where the correction is not folded in: 5 instead of 4 first-sweep rows
@@ -803,6 +804,7 @@ void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, con
     }
 #undef MG_J2
 #undef MG_J2K
+    return 0;
 }
 
 // one red-black Gauss-Seidel sweep (both colours) in one pass: out = RB(u)
@@ -932,10 +934,10 @@ template bool jacobi2_corr_slab_ok<double>(const Geom &, const Geom &);
 template bool jacobi2_corr_slab_ok<float>(const Geom &, const Geom &);
 template bool jacobi2_ok<double>(const Geom &);
 template bool jacobi2_ok<float>(const Geom &);
-template void launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *, bool, int);
+template int launch_jacobi2<double>(hipStream_t, const Geom &, const Coef<double> &, double, const double *, const double *, double *, bool, int, double *);
 template bool jacobi2_slab_ok<double>(const Geom &);
 template bool jacobi2_slab_ok<float>(const Geom &);
-template void launch_jacobi2<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *, bool, int);
+template int launch_jacobi2<float>(hipStream_t, const Geom &, const Coef<float> &, float, const float *, const float *, float *, bool, int, double *);
 template bool fast_path_ok<double>(const Geom &);
 template bool fast_path_ok<float>(const Geom &);
 template int fast_partials_capacity<double>(const Geom &);

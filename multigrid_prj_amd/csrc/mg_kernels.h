@@ -26,9 +26,11 @@ void launch_jacobi_fast(hipStream_t s, const Geom &g, const Coef<T> &c, T omega,
                         const T *rhs, T *out, bool zero_u);
 // two Jacobi sweeps in one pass (out = J(J(u))), see mg_jacobi_fast.hip
 template <typename T> bool jacobi2_ok(const Geom &g);
+// d_partials != nullptr: also sum (rhs - A u)^2 of the INPUT u, where the wide-tile kernel runs (returns the number of partial
+// sums written there, 0 = no norm was computed)
 template <typename T>
-void launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out,
-                    bool zero_u = false, int dup_planes = 0);  // dup_planes > 0: the same geometry once more, that many planes further up, in the same launch
+int launch_jacobi2(hipStream_t s, const Geom &g, const Coef<T> &c, T omega, const T *u, const T *rhs, T *out,
+                   bool zero_u = false, int dup_planes = 0, double *d_partials = nullptr);  // dup_planes > 0: the same geometry once more, that many planes further up, in the same launch
 // z-slab of a distributed level: the pair on its inner planes (launch_jacobi2 with g = planes 1 .. nz-2), see pair_on_slab_t
 template <typename T> bool jacobi2_slab_ok(const Geom &slab);
 // the same with the V-cycle's prolong-add folded in: out = J(J(u + P coarse)); u is not modified
@@ -43,9 +45,13 @@ template <typename T> bool jacobi2_corr_slab_ok(const Geom &gf, const Geom &gc);
 // coarse != nullptr: out = pair(u + P coarse); zero_u: u == 0; rb: one red-black sweep instead of two Jacobi sweeps
 template <typename T> bool pair_wide_ok(const Geom &g);
 void set_pair_wide(int mode);   // measurement tools only (tools/pairbench.hip): 0 = never, 1 = wherever the shape allows, -1 = default
+// d_partials != nullptr (plain Jacobi pair only): the launch also leaves one partial sum of (rhs - A u)^2 per workgroup
+// there -- the residual norm of the pair's INPUT; returns how many (0: not computed)
 template <typename T>
-void launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u, const T *coarse,
-                      const T *rhs, T *out, bool zero_u, bool rb, int dup_planes);
+int launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u, const T *coarse,
+                     const T *rhs, T *out, bool zero_u, bool rb, int dup_planes, double *d_partials = nullptr);
+// sum of n partial sums in a fixed order -> *d_out (mg_kernels.hip: k_reduce_final)
+void launch_reduce_final(hipStream_t s, const double *d_partials, long long n, double *d_out);
 // zebra line Gauss-Seidel along y: one colour pass; cp_den = the 2*ny factors of zebra_line_factors(cy, cd, ny) (device)
 template <typename T>
 void launch_zebra_y(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, T *u, const T *rhs, T *dp,

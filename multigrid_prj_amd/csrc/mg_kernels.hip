@@ -1510,6 +1510,11 @@ void launch_residual(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
     if (d_sumsq) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, d_partials, nb, d_sumsq);
 }
 
+void launch_reduce_final(hipStream_t s, const double *d_partials, long long n, double *d_out)
+{
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, s, d_partials, n, d_out);
+}
+
 template <typename T>
 void launch_sumsq(hipStream_t s, const Geom &g, const T *v, double *d_partials, double *d_sumsq)
 {

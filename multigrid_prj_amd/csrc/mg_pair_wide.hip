@@ -39,10 +39,15 @@ template <> struct WV<float> { static constexpr int V = 4; };
 
 // RB: the pipeline runs red-black Gauss-Seidel instead of Jacobi (see k_jacobi2): phase 1 = red half-sweep (black
 // points copied), phase 2 = black half-sweep on the plane behind -- ONE red-black sweep per pass
-template <typename T, int TPR, int G, bool DAMPED, bool CORR, bool ZEROU, bool RB = false>
+// NORM: the launch also returns sum r^2 of r = rhs - A u (the residual of the INPUT, Residual::apply_iteration_to_vec +
+// Norm of the reference, include/solvers.hpp:257-307): the first sweep has every operand of r in registers, so the outer
+// loop's convergence test (src/main.cpp:86-89) costs a few more instructions per point instead of a pass over HBM.
+// One partial sum per workgroup -> partials[blockIdx.x] (fixed order inside the workgroup; k_reduce_final adds them).
+template <typename T, int TPR, int G, bool DAMPED, bool CORR, bool ZEROU, bool RB = false, bool NORM = false>
 __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, const T *__restrict__ u_,
                                                    const T *__restrict__ rhs_, T *__restrict__ out_, int nby, int nbz,
-                                                   const T *__restrict__ coarse, Geom gc, int dup_planes)
+                                                   const T *__restrict__ coarse, Geom gc, int dup_planes,
+                                                   double *__restrict__ partials)
 {
     constexpr int V = WV<T>::V, CV = V / 2, NR = CV + 1;
     constexpr int R = 2, NROW = G * R, S = NROW - 2;
@@ -52,11 +57,15 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
     // u planes p (read) / p+1 (written): rows 1 .. NROW = the tile, row 0 / NROW+1 = the halo rows below / above it
     __shared__ __align__(16) T su[ZEROU ? 1 : 2][ZEROU ? 1 : NROW + 2][ZEROU ? V : LP];
     __shared__ __align__(16) T sv[2][NROW][LP];  // first-sweep planes p-1 (read) / p (written)
+    __shared__ double snorm[NORM ? TPR * G / 64 : 1];
 
     const int nblocks = nby * nbz, ntotal = dup_planes > 0 ? 2 * nblocks : nblocks;
     const int per = (ntotal + 7) >> 3;
     int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order
-    if (bid >= ntotal) return;                             // whole workgroup
+    if (bid >= ntotal) {                                   // whole workgroup
+        if (NORM && threadIdx.x == 0) partials[blockIdx.x] = 0.;
+        return;
+    }
     const bool second = bid >= nblocks;
     if (second) { bid -= nblocks; g.gz0 += dup_planes; }
     const long long dup_off = second ? (long long)dup_planes * g.plane : 0;
@@ -215,6 +224,31 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
         return res;
     };
 
+    // sum over the vector of (rhs - A u)^2, the reference's residual expression term by term (k_sweep3d<OP_RESIDUAL>): the
+    // products and the first three partial sums are the update's own
+    auto resid_sq = [&](const vec &zm, const vec &cc, const vec &zp, const vec &ym, const vec &yp, T xm, T xp,
+                        const vec &bb, bool rb) {
+        double sq = 0.;
+#pragma unroll
+        for (int e = 0; e < V; e++) {
+            const T left = (e == 0) ? xm : cc[e > 0 ? e - 1 : 0];
+            const T right = (e == V - 1) ? xp : cc[e < V - 1 ? e + 1 : 0];
+            T sum = 0;
+            sum += c.cz * zm[e];
+            sum += c.cy * ym[e];
+            sum += c.cx * left;
+            sum += c.cd * cc[e];
+            sum += c.cx * right;
+            sum += c.cy * yp[e];
+            sum += c.cz * zp[e];
+            if (rb || (x0 + e == 0)) sum = (T)1 * cc[e];
+            const T res = bb[e] - sum;
+            sq += (double)res * (double)res;
+        }
+        return sq;
+    };
+    double nsq = 0.;
+
     vec um[R], uc[R], up[R], vm[R], vc[R], bq[R];
     // ---- prologue: planes z0-2 and z0-1 of u (corrected), plane z0-1 published
     {
@@ -299,7 +333,7 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
         for (int r = 0; r < R; r++) { up[r] = nu[r]; b[r] = nb[r]; ter_n[r] = nter[r]; vtail[r] = nvt[r]; }
         T Ra[3][NR], Rb[3][NR];
         if (CORR) raw(p + 1, Ra, Rb);
-        else fetch(p + 2, p + 1);
+        else if (!NORM) fetch(p + 2, p + 1);
         // ---- u(p+1) + P e -> LDS slot (p+1)&1 (read by the next step's first sweep)
         if (CORR) {
             T Z[3][NR];
@@ -338,6 +372,13 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
                 const vec ym = (r == 0) ? yo : uc[0];
                 const vec yp = (r == 0) ? uc[1] : yo;
                 v[r] = update(um[r], uc[r], up[r], ym, yp, xm, xp, b[r], zbp || ybnd[r]);
+                if (NORM && outrow[r] && p >= z0 && p < z1) {   // every point of the piece belongs to exactly one tile's output rows
+                    nsq += resid_sq(um[r], uc[r], up[r], ym, yp, xm, xp, b[r], zbp || ybnd[r]);
+                    if (tail) {   // Dirichlet column nx-1: r = rhs - 1 * u
+                        const T rt = vtail[r] - (T)1 * xp;
+                        nsq += (double)rt * (double)rt;
+                    }
+                }
                 if (RB) {
 #pragma unroll
                     for (int e = 0; e < V; e++)
@@ -347,6 +388,7 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
                 if (tail) sv[sc][i0 + r][V + x0 + V] = vtail[r];
             }
         }
+        if (NORM) fetch(p + 2, p + 1);   // (the residual's extra live values would not fit beside the next operands any earlier)
         // ---- second sweep on plane q = p-1, output rows
         const int q = p - 1;
         if (q >= z0 && q < z1) {
@@ -387,6 +429,17 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; r++) { um[r] = uc[r]; uc[r] = up[r]; vm[r] = vc[r]; vc[r] = v[r]; bq[r] = b[r]; }
+    }
+    if (NORM) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nsq += __shfl_down(nsq, off, 64);
+        if (lane == 0) snorm[t >> 6] = nsq;
+        __syncthreads();
+        if (t == 0) {
+            double tot = 0.;
+            for (int w = 0; w < TPR * G / 64; w++) tot += snorm[w];
+            partials[blockIdx.x] = tot;
+        }
     }
 }
 
@@ -429,8 +482,8 @@ bool pair_wide_ok(const Geom &g)
 }
 
 template <typename T>
-void launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u, const T *coarse,
-                      const T *rhs, T *out, bool zero_u, bool rb, int dup)
+int launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T> &c, T omega, const T *u, const T *coarse,
+                     const T *rhs, T *out, bool zero_u, bool rb, int dup, double *d_partials)
 {
     constexpr int V = WV<T>::V;
     const int tpr = (g.nx - 1) / V;
@@ -441,10 +494,14 @@ void launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T
     const int grid = ((ncopy * nby * nbz + 7) / 8) * 8;
     const bool damped = (omega != (T)1) && !rb;
 #define MG_PW(TPR, GG, D, C, Z, RBB) \
-    hipLaunchKernelGGL((k_pairw<T, TPR, GG, D, C, Z, RBB>), dim3(grid), dim3(TPR * GG), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, dup)
+    hipLaunchKernelGGL((k_pairw<T, TPR, GG, D, C, Z, RBB>), dim3(grid), dim3(TPR * GG), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, dup, (double *)nullptr)
+#define MG_PWN(TPR, GG, D) \
+    hipLaunchKernelGGL((k_pairw<T, TPR, GG, D, false, false, false, true>), dim3(grid), dim3(TPR * GG), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, dup, d_partials)
+    const bool norm = d_partials && !rb && !coarse && !zero_u;
 #define MG_PW_SHAPE(TPR, GG) \
     do { \
-        if (rb) { if (coarse) MG_PW(TPR, GG, false, true, false, true); else MG_PW(TPR, GG, false, false, false, true); } \
+        if (norm) { if (damped) MG_PWN(TPR, GG, true); else MG_PWN(TPR, GG, false); } \
+        else if (rb) { if (coarse) MG_PW(TPR, GG, false, true, false, true); else MG_PW(TPR, GG, false, false, false, true); } \
         else if (coarse) { if (damped) MG_PW(TPR, GG, true, true, false, false); else MG_PW(TPR, GG, false, true, false, false); } \
         else if (zero_u) { if (damped) MG_PW(TPR, GG, true, false, true, false); else MG_PW(TPR, GG, false, false, true, false); } \
         else { if (damped) MG_PW(TPR, GG, true, false, false, false); else MG_PW(TPR, GG, false, false, false, false); } \
@@ -454,11 +511,13 @@ void launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T
     else MG_PW_SHAPE(128, 8);
 #undef MG_PW_SHAPE
 #undef MG_PW
+#undef MG_PWN
+    return norm ? grid : 0;   // partial sums written (one per workgroup launched)
 }
 
 template bool pair_wide_ok<double>(const Geom &);
 template bool pair_wide_ok<float>(const Geom &);
-template void launch_pair_wide<double>(hipStream_t, const Geom &, const Geom &, const Coef<double> &, double, const double *, const double *, const double *, double *, bool, bool, int);
-template void launch_pair_wide<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, float, const float *, const float *, const float *, float *, bool, bool, int);
+template int launch_pair_wide<double>(hipStream_t, const Geom &, const Geom &, const Coef<double> &, double, const double *, const double *, const double *, double *, bool, bool, int, double *);
+template int launch_pair_wide<float>(hipStream_t, const Geom &, const Geom &, const Coef<float> &, float, const float *, const float *, const float *, float *, bool, bool, int, double *);
 
 }  // namespace mg

@@ -902,9 +902,15 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
                 if (s == 0 && corr_level >= 0)
                     launch_jacobi2_corr<T>(stream_, L.g, lv_[corr_level].g, c, (T)d_.omega, ptr<T>(ax, level),
                                            ptr<T>(ax, corr_level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level));
-                else  // x_zero: the pair starts from an implicit zero guess (nothing is read for x)
-                    launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
-                                      x_zero && s == 0);
+                else {  // x_zero: the pair starts from an implicit zero guess (nothing is read for x)
+                    const bool norm = want_pair_norm_ && level == 0 && s == 0 && !x_zero && ax == MG_ARR_U && ar == MG_ARR_RHS;
+                    const int np = launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level),
+                                                     ptr<T>(MG_ARR_TMP, level), x_zero && s == 0, 0, norm ? d_partials_ : (double *)nullptr);
+                    if (norm && np > 0) {   // sum r^2 of the pair's input -> d_scal_[0]
+                        launch_reduce_final(stream_, d_partials_, np, d_scal_);
+                        pair_norm_done_ = true;
+                    }
+                }
                 std::swap(L.base[ax], L.base[MG_ARR_TMP]);
                 s++; launches++;
                 continue;
@@ -1270,7 +1276,8 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
         MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
     } else if (mine) {
-        MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero, -1, true));
+        if (l == 0 && fine_pre_done_) fine_pre_done_ = false;   // Solver::solve ran this level's pre-smoothing with the norm
+        else MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero, -1, true));
         if (prof) MG_TRY(prof_begin(l));
         if (!fuse_rr && !fuse_rr_slab) MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
     }
@@ -1410,6 +1417,19 @@ int Solver::cycle_async(int count)
     return MG_OK;
 }
 
+// The residual norm of main.cpp:86 can ride on the next cycle's first launch when that launch is the wide-tile Jacobi pair on
+// an undistributed finest level (its first sweep holds every operand of rhs - A u): V-cycle, exactly two pre-smoothing sweeps,
+// nothing between the norm and the cycle (no outer Gauss-Seidel sweeps, no stage dumps, no profiling brackets).
+template <typename T>
+bool Solver::pair_norm_ok() const
+{
+    static const bool enabled = [] { const char *e = getenv("MG_PAIR_NORM"); return !(e && e[0] == '0'); }();
+    const Level &L = lv_[0];
+    return enabled && d_.cycle == MG_CYCLE_V && d_.levels > 1 && d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre == 2 &&
+           d_.outer_pre_gs == 0 && !stage_fn_ && !profiling_ && L.present && !L.dist && nranks_ == 1 &&
+           jacobi2_ok<T>(L.g) && pair_wide_ok<T>(L.g);
+}
+
 // Outer loop of src/main.cpp:72-116.
 int Solver::solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist,
                   mg_cycle_stats *per_cycle, const int *lock_counts, int n_lock)
@@ -1417,6 +1437,48 @@ int Solver::solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist
     MG_HIP(hipSetDevice(device_));
     double nb = 0, nr = 0;
     MG_TRY(sumsq(0, MG_ARR_RHS, &nb));                       // Residual ctor, solvers.hpp:237-242
+    const bool fused_norm = !lock_counts && (d_.dtype == MG_F64 ? pair_norm_ok<double>() : pair_norm_ok<float>());
+    if (fused_norm) {
+        // Same loop, same history: entry k is the norm after k cycles. It is computed by the first pre-smoothing pair of cycle
+        // k + 1, which runs before the test; when the test says stop (or maxit is reached) that pair's output is dropped -- it
+        // was written out of place, U still holds the iterate the norm belongs to.
+        Level &L0 = lv_[0];
+        int nh = 0;
+        for (int it = 0; it <= maxit; it++) {
+            void *const base_u = L0.base[MG_ARR_U], *const base_t = L0.base[MG_ARR_TMP];
+            want_pair_norm_ = true; pair_norm_done_ = false;
+            const int rc = d_.dtype == MG_F64 ? smooth_t<double>(0, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, false, -1, true)
+                                              : smooth_t<float>(0, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, false, -1, true);
+            want_pair_norm_ = false;
+            MG_TRY(rc);
+            if (!pair_norm_done_) { set_last_error("mg_solve: the pre-smoothing pair did not deliver the residual norm"); return MG_ERR_HIP; }
+            MG_HIP(hipMemcpyAsync(h_scal_, d_scal_, sizeof(double), hipMemcpyDeviceToHost, stream_));
+            MG_HIP(hipStreamSynchronize(stream_));
+            nr = h_scal_[0];
+            if (per_cycle && it > 0) {                       // the coarse solver's record of the cycle that has just finished
+                mg_cycle_stats &st = per_cycle[it - 1];
+                st.coarse_iters = h_coarse_->iters;
+                st.coarse_flag = h_coarse_->flag;
+                st.coarse_relres = h_coarse_->relres;
+                st.fine_sumsq_r = 0.0;
+            }
+            const double rel = std::sqrt(nr / nb);
+            if (hist && nh < hist_cap) hist[nh] = rel;
+            nh++;
+            if ((it > 0 && rel <= tol) || it == maxit) {     // main.cpp:88-89 / the loop bound: drop the speculative pair
+                L0.base[MG_ARR_U] = base_u; L0.base[MG_ARR_TMP] = base_t;
+                break;
+            }
+            fine_pre_done_ = true;
+            const int crc = cycle_enqueue();
+            fine_pre_done_ = false;
+            MG_TRY(crc);
+            if (per_cycle) MG_HIP(hipMemcpyAsync(h_coarse_, d_coarse_, sizeof(CoarseOut), hipMemcpyDeviceToHost, stream_));
+        }
+        MG_HIP(hipStreamSynchronize(stream_));
+        if (n_hist) *n_hist = nh;
+        return MG_OK;
+    }
     MG_TRY(residual(0, MG_ARR_U, MG_ARR_RHS, -1, &nr));      // main.cpp:73-74
     int nh = 0;
     if (hist && nh < hist_cap) hist[nh] = std::sqrt(nr / nb);

@@ -266,6 +266,46 @@ def test_vcycle_headline_size_513_bit_exact(smoother):
         assert np.array_equal(sg.get_solution(), so.get_solution())
 
 
+@pytest.mark.parametrize("n,dtype,levels", [(257, capi.MG_F64, 5), (513, capi.MG_F32, 6)])
+def test_solve_takes_the_residual_norm_inside_the_next_pre_smoothing_pair(n, dtype, levels):
+    """mg_solve on a level wide enough for the wide-tile pair (mg_pair_wide.hip: NORM) computes each history entry inside the
+    first pre-smoothing pair of the NEXT cycle and drops the speculative pair when the loop stops (src/main.cpp:86-89). The
+    outer loop done by hand -- mg_cycle + mg_residual per iteration, the separate norm kernel -- must give the same history
+    (summation order differs: rtol), the same number of entries when the tolerance stops the loop, and the same iterate BIT
+    FOR BIT; a cycle after the solve must continue from that iterate."""
+    kw = dict(dim=3, n=n, levels=levels, dtype=dtype, length=1.0, alpha=1.0, cycle=capi.CYCLE_V, nu_pre=2, nu_post=2,
+              smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW,
+              coarse_mode=capi.COARSE_FIXED, coarse_maxit=20, outer_pre_gs=0)
+    b = po.fill_rhs_3d(n, 1.0, 1.0, 1)
+    if dtype == capi.MG_F32:
+        b = b.astype(np.float32)
+    rtol = 1e-12 if dtype == capi.MG_F64 else 1e-5
+    with capi.Solver(capi.make_desc(**kw)) as s1, capi.Solver(capi.make_desc(**kw)) as s2:
+        s1.set_rhs(b); s2.set_rhs(b)
+        nb = s2.sumsq(0, capi.ARR_RHS)
+        hand = [np.sqrt(s2.residual(0, capi.ARR_U, capi.ARR_RHS, -1) / nb)]
+        hand_iters = []
+        for _ in range(3):
+            hand_iters.append(s2.cycle().coarse_iters)
+            hand.append(np.sqrt(s2.residual(0, capi.ARR_U, capi.ARR_RHS, -1) / nb))
+        hist, stats = s1.solve(0.0, 3)
+        assert len(hist) == 4 and [st.coarse_iters for st in stats] == hand_iters
+        np.testing.assert_allclose(hist, hand, rtol=rtol)
+        assert np.array_equal(s1.get_solution(), s2.get_solution())
+        # the tolerance stops the loop after the same cycle
+        tol = float(np.sqrt(hand[1] * hand[2]))
+        s1.zero_array(capi.ARR_U, 0); s2.zero_array(capi.ARR_U, 0)
+        hist, _ = s1.solve(tol, 10)
+        assert len(hist) == 3 and hist[-1] <= tol < hist[-2]
+        np.testing.assert_allclose(hist, hand[:3], rtol=rtol)
+        for _ in range(2):
+            s2.cycle()
+        assert np.array_equal(s1.get_solution(), s2.get_solution())
+        # and the solver carries on from there
+        s1.cycle(); s2.cycle()
+        assert np.array_equal(s1.get_solution(), s2.get_solution())
+
+
 @pytest.mark.parametrize("smoother", [capi.SMOOTH_JACOBI, capi.SMOOTH_RBGS])
 def test_config5_anisotropic_semi_coarsened_513_bit_exact(smoother):
     """BASELINE config 5 at full size: -(dxx + dyy + 0.01 dzz) on 513^3, 8 levels of which the first three

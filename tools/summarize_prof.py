@@ -38,7 +38,11 @@ def main():
         gsz = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
         wsz = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
         groups[(short(r["Kernel_Name"]), gsz, wsz)].append(
-            (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size")))
+            (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+             # rocprofv3's VGPR_Count on gfx950 is HALF the allocation (granule 8): checked against hipcc's
+             # -Rpass-analysis=kernel-resource-usage for five kernels (165 -> 84, 124 -> 64, 117 -> 60, 82 -> 44, 76 -> 40);
+             # the column printed is the allocation = 2 x VGPR_Count (+ accumulation registers: none in this library)
+             2 * int(r.get("VGPR_Count") or 0) + int(r.get("Accum_VGPR_Count") or 0), r.get("SGPR_Count"), r.get("LDS_Block_Size")))
     total = sum(sum(d for d, *_ in v) for v in groups.values())
     pmc = {}
     for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
@@ -65,7 +69,7 @@ def main():
         lines += [f"bench line of the traced run: value={bench['value']:.2f} {bench['unit']}, ms_per_step={bench['ms_per_step']:.3f}, "
                   f"in-region smoother sweep {bench['roofline']['sweep_ms']:.4f} ms = {bench['roofline']['achieved']:.0f} GB/s "
                   f"(frac {bench['roofline']['frac']:.3f})", "", f"workload: {bench['config']['workload']}", ""]
-    lines += ["| kernel | grid (threads) | wg | calls | avg µs | min µs | total ms | % | VGPR | read MB/launch (2×FETCH) | write MB/launch |",
+    lines += ["| kernel | grid (threads) | wg | calls | avg µs | min µs | total ms | % | VGPRs allocated | read MB/launch (2×FETCH) | write MB/launch |",
               "|---|---|---|---|---|---|---|---|---|---|---|"]
     rows_csv = [("kernel", "grid_threads", "wg", "calls", "avg_us", "min_us", "total_ms", "pct", "vgpr", "read_MB", "write_MB")]
     for key, v in sorted(groups.items(), key=lambda kv: -sum(d for d, *_ in kv[1])):
