@@ -107,6 +107,13 @@ def launch(a, argv):
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=(r == 0)))
     deadline = time.monotonic() + a.launch_timeout
     failed = None
+    # rank 0's pipe is drained by a thread from the start: a rank 0 that writes more than a pipe buffer before the other
+    # ranks finish must not stall against a parent that only polls
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    out0 = ""
     try:
         while True:
             codes = [p.poll() for p in procs]
@@ -114,22 +121,15 @@ def launch(a, argv):
             if bad:
                 failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
                 break
-            # rank 0 is drained by communicate() below; the others are only polled
-            if all(c == 0 for c in codes[1:]):
+            if all(c == 0 for c in codes):
                 break
             if time.monotonic() > deadline:
                 failed = f"ranks still running after {a.launch_timeout:.0f} s"
                 break
             time.sleep(0.05)
-        out0 = ""
         if failed is None:
-            try:
-                out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.monotonic()))
-            except subprocess.TimeoutExpired:
-                failed = f"rank 0 still running after {a.launch_timeout:.0f} s"
-            else:
-                if procs[0].returncode != 0:
-                    failed = f"rank 0 exited with code {procs[0].returncode}"
+            reader.join(timeout=10)
+            out0 = "".join(c for c in chunks if c)
     finally:
         for p in procs:          # the exact children we started, nothing by pattern
             if p.poll() is None:
@@ -340,8 +340,14 @@ def main():
     sweeps_timed = sm_sweeps                            # sweeps those launches performed
     launch_ms = sm_ms / max(sm_launches, 1)
     sweeps_per_launch = sweeps_timed / max(sm_launches, 1)
-    achieved = sweep_bytes / (launch_ms * 1e-3) / 1e9 if sm_launches else 0.0
+    # a launch that does less than a sweep (one colour pass of a zebra line smoother: half a sweep) is priced per FULL sweep:
+    # 24 B/pt against the time of the launches that make one sweep
+    bytes_per_launch = sweep_bytes * min(sweeps_per_launch, 1.0) if sm_launches else 0.0
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if sm_launches else 0.0
     fused_pair = sweeps_per_launch > 1.5
+    vlen = 2 if a.dtype == "f64" else 4
+    wide = world == 1 and (a.n - 1) % vlen == 0 and (a.n - 1) // vlen in (128, 256) and os.environ.get("MG_PAIR_WIDE", "1") != "0"
+    pair_kernel = "k_pairw (wide tiles, mg_pair_wide.hip)" if wide else "k_jacobi2"
 
     traffic_rows = profiled_traffic(a) if world == 1 else {}
     tr = traffic_rows.get("pair" if fused_pair else "single")
@@ -364,7 +370,7 @@ def main():
     pts_c = ((a.n + 1) // 2) ** 2 * (a.n if a.semi else (a.n + 1) // 2)
     kernels = [k for k in (
         # J(J(u + P e)): reads u, the coarse correction (1/8 of the points) and rhs, writes once
-        priced("SMOOTH_PROLONG", "post-smoothing launch that also applies the coarse correction (k_jacobi2<CORR>)",
+        priced("SMOOTH_PROLONG", f"post-smoothing launch that also applies the coarse correction ({pair_kernel}, CORR)",
                sweep_bytes + esz * pts_c, 2 * sweep_bytes + 2 * esz * pts_local + esz * pts_c, "corr"),
         # R(rhs - A u): reads u and rhs, writes the coarse right-hand side
         priced("RESID_RESTRICT", "finest-level residual + full-weighting restriction (k_resid_restrict_fw)",
@@ -395,19 +401,21 @@ def main():
                            if world > 1 else None),
         "ms_per_step_with_residual_norm": solve_ms_per_cycle,
         "roofline": {"bound": "hbm",
-                     "kernel": ((f"finest-grid fused double Jacobi sweep k_jacobi2 ({a.n}^3, two sweeps in one pass over HBM)" if fused_pair
+                     "kernel": ((f"finest-grid fused double {'red-black half-' if a.smoother == 'rbgs' else 'Jacobi '}sweep {pair_kernel} ({a.n}^3, one pass over HBM)" if fused_pair
                                  else f"finest-grid {a.smoother} sweep ({a.n}^3)")
                                 + (f"; rank 0's z-slab of {nz} planes, one segment = halo exchange + interior + boundary launches" if world > 1 else "")),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "traffic_source": tr["source"] if tr else None,
                      "launch_ms": launch_ms, "launches_timed": sm_launches, "sweeps_per_launch": sweeps_per_launch,
-                     "compulsory_bytes_per_launch": sweep_bytes,
+                     "compulsory_bytes_per_launch": int(bytes_per_launch),
                      "sweep_ms": launch_ms / sweeps_per_launch,
                      "sweep_equivalent_gbps": sweeps_per_launch * sweep_bytes / (launch_ms * 1e-3) / 1e9,
                      "note": ("achieved = 24 B/pt (read u, read rhs, write once) / launch time: the launch makes one pass for "
                               "two sweeps; sweep_equivalent_gbps = what two streaming sweeps would have moved per second "
-                              "of it" if fused_pair else None)},
+                              "of it" if fused_pair else
+                              ("a launch is one colour pass = half a sweep: achieved = 24 B/pt / (2 x launch time), the full sweep's rate"
+                               if sweeps_per_launch < 1 else None))},
         "smoother_gbps": achieved,
         "kernels": kernels,
         "streaming_sweep": ({"kernel": f"single Jacobi sweep k_sweep3d ({a.n}^3), timed after the region", "launch_ms": stream_ms,
@@ -439,12 +447,29 @@ def profiled_traffic(a):
     separate --pmc FETCH_SIZE / WRITE_SIZE passes, read = 2 x FETCH_SIZE x 1024 on gfx950). Counters cannot
     be collected inside a timed run, so this is not live; rows are picked by exact template signature and
     the finest grid's launch size. Empty when the workload is not the profiled default."""
-    if not (a.n == 513 and a.dtype == "f64" and a.smoother == "jacobi" and a.levels == 6 and not a.semi):
-        return {}
     import csv
     import glob
+    import re
+    # which committed summaries belong to this workload: the default command's are profiles/r<NN>[x]_[unfused_]kernel_summary.csv,
+    # the other configurations' carry a tag (tools/profile.sh <tag> <bench args>)
+    default = a.n == 513 and a.dtype == "f64" and a.smoother == "jacobi" and a.levels == 6 and not a.semi \
+        and a.aniso_eps == 1.0 and a.aniso_x == 1.0 and a.aniso_y == 1.0
+    if default:
+        pat = re.compile(r"r\d+[a-z]?_(unfused_)?kernel_summary\.csv$")
+    elif a.n == 513 and a.dtype == "f64" and a.smoother == "rbgs" and a.levels == 6 and not a.semi:
+        pat = re.compile(r"r\d+[a-z]?_config3_rbgs_kernel_summary\.csv$")
+    elif a.n == 1025 and a.dtype == "f32" and a.smoother == "jacobi" and a.levels == 7:
+        pat = re.compile(r"r\d+[a-z]?_config4_grid_kernel_summary\.csv$")
+    elif a.n == 513 and a.dtype == "f64" and a.smoother == "zebra" and a.semi == 3:
+        pat = re.compile(r"r\d+[a-z]?_config5_semi_zebra_kernel_summary\.csv$")
+    else:
+        return {}
+    T = "double" if a.dtype == "f64" else "float"
+    lanes = str((a.n - 1) // (2 if a.dtype == "f64" else 4))
     rows = {}
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_summary*.csv"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_summary.csv"))):
+        if not pat.search(os.path.basename(path)):
+            continue
         src = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc passes of this command)"
         best = {}
         for r in csv.DictReader(open(path)):
@@ -452,22 +477,30 @@ def profiled_traffic(a):
                 continue
             t = _template_args(r["kernel"])
             key = None
-            if r["kernel"].startswith("k_jacobi2<") and t[:2] == ["double", "256"]:
-                # <T, TPR, DAMPED, NTLOAD, CORR, RB, ZEROU, TYO>
-                if t[4:7] == ["false", "false", "false"]:
+            if r["kernel"].startswith("k_pairw<") and t[:2] == [T, lanes]:
+                # <T, TPR, G, DAMPED, CORR, ZEROU, RB[, NORM]>
+                if t[4:6] == ["false", "false"]:
                     key = "pair"
-                elif t[4:7] == ["true", "false", "false"]:
+                elif t[4:6] == ["true", "false"]:
                     key = "corr"
-            elif r["kernel"].startswith("k_sweep3d<") and t[:2] == ["double", "0"] and t[-1] == "false":
+            elif r["kernel"].startswith("k_jacobi2<") and t[:2] == [T, lanes]:
+                # <T, TPR, DAMPED, NTLOAD, CORR, RB, ZEROU, TYO>
+                if t[4] == "false" and t[6] == "false":
+                    key = "pair"
+                elif t[4] == "true" and t[6] == "false":
+                    key = "corr"
+            elif r["kernel"].startswith("k_zebra_") and t[:1] == [T]:
+                key = "pair" if "pair" not in best or int(r["grid_threads"]) > int(best["pair"]["grid_threads"]) else None
+            elif r["kernel"].startswith("k_sweep3d<") and t[:2] == [T, "0"] and t[-1] == "false":
                 key = "single"
-            elif r["kernel"].startswith("k_resid_restrict_fw<") and t[:1] == ["double"]:
+            elif r["kernel"].startswith("k_resid_restrict_fw<") and t[:1] == [T]:
                 key = "rr"
-            elif r["kernel"].startswith("k_prolong3d_fast<") and t[:1] == ["double"]:
+            elif r["kernel"].startswith("k_prolong3d_fast<") and t[:1] == [T]:
                 key = "prolong"
             if key and (key not in best or int(r["grid_threads"]) > int(best[key]["grid_threads"])):
                 best[key] = r
         for key, r in best.items():   # later rounds' files win
-            if key == "single" and int(r["grid_threads"]) < 10_000_000:
+            if key == "single" and default and int(r["grid_threads"]) < 10_000_000:
                 continue              # only a finest-grid launch (11.4 M threads) prices the streaming sweep
             rows[key] = {"bytes": (float(r["read_MB"]) + float(r["write_MB"])) * 1e6, "source": src, "kernel": r["kernel"]}
     return rows

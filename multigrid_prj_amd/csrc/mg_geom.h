@@ -101,6 +101,27 @@ __device__ __forceinline__ void div_cd_n(const T (&a)[N], T (&q)[N], const Coef<
         for (int e = 0; e < N; e++) q[e] = a[e] / c.cd;
     }
 }
+
+// The same with a WAVE-uniform test: the three-operation quotients run for every lane with the full execution mask (the
+// per-lane test above makes the compiler wrap them in execution-mask regions, 8-10 scalar instructions per group); when ANY
+// lane of the wave fell outside the window the whole wave redoes the group with the hardware division -- same bits for the
+// lanes that were inside it.
+template <typename T, int N>
+__device__ __forceinline__ void div_cd_n_wave(const T (&a)[N], T (&q)[N], const Coef<T> &c)
+{
+    bool ok = true;
+#pragma unroll
+    for (int e = 0; e < N; e++) {
+        const T q0 = a[e] * c.rcd;
+        const T r = dev_fma(-q0, c.cd, a[e]);
+        q[e] = dev_fma(r, c.rcd, q0);
+        ok = ok && ((dev_biased_exponent(a[e]) - DivWindow<T>::lo) < c.win);
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ull, 0)) {
+#pragma unroll
+        for (int e = 0; e < N; e++) q[e] = a[e] / c.cd;
+    }
+}
 #endif
 
 struct CoarseOut {

@@ -33,6 +33,14 @@
 namespace mg {
 namespace {
 
+// value of lane l (a compile-time constant) in every lane: v_readlane, no LDS
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_bcast(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 template <typename T> struct WV;
 template <> struct WV<double> { static constexpr int V = 2; };
 template <> struct WV<float> { static constexpr int V = 4; };
@@ -214,7 +222,10 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
             sum += c.cz * zp[e];
             num[e] = bb[e] - sum;
         }
-        div_cd_n<T, V>(num, quo, c);
+        // wave-uniform fallback test in fp64 (fewer execution-mask regions: -2 % per launch at 513^3); the per-lane form in
+        // fp32, where the uniform form's longer live ranges spill (1025^3 pair 2.6 -> 3.1 ms)
+        if constexpr (sizeof(T) == 8) div_cd_n_wave<T, V>(num, quo, c);
+        else div_cd_n<T, V>(num, quo, c);
 #pragma unroll
         for (int e = 0; e < V; e++) {
             T jac = quo[e];
@@ -304,23 +315,25 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
     // (all 16 waves of the tile meet at one barrier per plane: without it the CU alternates between waiting and computing).
     vec nu[R], nb[R], nh = (vec)(0);
     T nter[R], nvt[R], nhter = 0;
+    T vtq[R] = {0, 0};   // rhs of the Dirichlet column on plane q (the row's last thread): goes out with the second sweep
     auto fetch = [&](int pu1, int pb) {   // raw u of plane pu1 (rows, halo row, tail column) and rhs of plane pb
         const long long pn = plane_of(pu1), po = plane_of(pb);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             nu[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (pn + urow[r])) + x0);
-            nter[r] = 0;
-            if (tail && !ZEROU) nter[r] = (u + (pn + urow[r]))[x0 + V];
-        }
-        if (!ZEROU && (lo_grp || hi_grp)) {
-            nh = *(const vec *)((u + (pn + hrow)) + x0);
-            if (tail) nhter = (u + (pn + hrow))[x0 + V];
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
             nb[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
-            nvt[r] = 0;
-            if (tail) nvt[r] = (rhs + (po + urow[r]))[x0 + V];  // first sweep on the Dirichlet column: v = rhs
+        }
+        if (!ZEROU && (lo_grp || hi_grp)) nh = *(const vec *)((u + (pn + hrow)) + x0);
+        // the Dirichlet column nx-1 (the row's last thread): ONE predicated region for all its values
+#pragma unroll
+        for (int r = 0; r < R; r++) { nter[r] = 0; nvt[r] = 0; }
+        if (tail) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (!ZEROU) nter[r] = (u + (pn + urow[r]))[x0 + V];
+                nvt[r] = (rhs + (po + urow[r]))[x0 + V];  // first sweep on the Dirichlet column: v = rhs
+            }
+            if (!ZEROU && (lo_grp || hi_grp)) nhter = (u + (pn + hrow))[x0 + V];
         }
     };
     fetch(z0, z0 - 1);
@@ -346,13 +359,17 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
         if constexpr (!ZEROU) {
             const int sn = (p + 1) & 1;
 #pragma unroll
+            for (int r = 0; r < R; r++) *(vec *)&su[sn][1 + i0 + r][V + x0] = up[r];
+            if (lo_grp || hi_grp) *(vec *)&su[sn][hs][V + x0] = hn;
+        }
+        if (tail) {   // the Dirichlet column: u(p+1) and v(p) = rhs(p) in one predicated region
+#pragma unroll
             for (int r = 0; r < R; r++) {
-                *(vec *)&su[sn][1 + i0 + r][V + x0] = up[r];
-                if (tail) su[sn][1 + i0 + r][V + x0 + V] = ter_n[r];
+                if constexpr (!ZEROU) su[(p + 1) & 1][1 + i0 + r][V + x0 + V] = ter_n[r];
+                sv[p & 1][i0 + r][V + x0 + V] = vtail[r];
             }
-            if (lo_grp || hi_grp) {
-                *(vec *)&su[sn][hs][V + x0] = hn;
-                if (tail) su[sn][hs][V + x0 + V] = hter_n;
+            if constexpr (!ZEROU) {
+                if (lo_grp || hi_grp) su[(p + 1) & 1][hs][V + x0 + V] = hter_n;
             }
         }
         // ---- first sweep on plane p, both rows
@@ -385,7 +402,6 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
                         if (((x0 + e + Y0 + i0 + r + gzo + p) & 1) != 0) v[r][e] = uc[r][e];  // not red: unchanged
                 }
                 *(vec *)&sv[sc][i0 + r][V + x0] = v[r];
-                if (tail) sv[sc][i0 + r][V + x0 + V] = vtail[r];
             }
         }
         if (NORM) fetch(p + 2, p + 1);   // (the residual's extra live values would not fit beside the next operands any earlier)
@@ -411,6 +427,7 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
                     }
                     __builtin_nontemporal_store(res, (vec *)((out + (qo + urow[r])) + x0));
                     constexpr int LINE = 128 / (int)sizeof(T), TLN = LINE / V;  // lanes that write the tail line
+                    const T vq63 = lane_bcast(vtq[r], 63);   // rhs(q, row, nx-1) in the tail wave: its last thread fetched it one step ago
                     if (tailwave && lane >= 64 - TLN) {
                         // column nx-1 (Dirichlet) as one full 128-byte line: value + zero padding
                         const int j = lane - (64 - TLN);
@@ -419,7 +436,7 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
                         if (xs < line_end) {
                             const long long rb0 = qo + urow[r];
                             vec tv = (vec)(0);
-                            if (j == 0) tv[0] = rhs[rb0 + g.nx - 1];
+                            if (j == 0) tv[0] = vq63;
                             __builtin_nontemporal_store(tv, (vec *)(out + rb0 + xs));
                         }
                     }
@@ -428,7 +445,7 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < R; r++) { um[r] = uc[r]; uc[r] = up[r]; vm[r] = vc[r]; vc[r] = v[r]; bq[r] = b[r]; }
+        for (int r = 0; r < R; r++) { um[r] = uc[r]; uc[r] = up[r]; vm[r] = vc[r]; vc[r] = v[r]; bq[r] = b[r]; vtq[r] = vtail[r]; }
     }
     if (NORM) {
 #pragma unroll

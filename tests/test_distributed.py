@@ -196,7 +196,7 @@ def test_hip_distributed_zebra_line_smoother(world, n, levels, direction, tmp_pa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
 def test_hip_semi_coarsening_plus_zebra_lines_on_1_2_3_ranks(world, tmp_path):
     """BASELINE config 5 as worded, in miniature (n = 129): semi-coarsening for the weak z-coupling AND zebra line
     Gauss-Seidel along the dominant y direction. The slabs cut z, the lines run along y and the semi-coarsened levels
@@ -321,6 +321,35 @@ def test_rccl_transport_carries_the_distributed_cycle(world, n, levels, dtype, r
         np.testing.assert_allclose(h, h1, rtol=1e-12 if dtype == 0 else 1e-6)
     if not rb and n >= 257:   # Jacobi V(2,2), rows wide enough for the fused slab kernels: the finest level's post-smoothing pair folded the prolongation in
         assert all(int(p["fold_launches"]) == 2 and int(p["prolong_launches"]) == 0 for p in _run_ranks.last_parts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,replicate", [("hip", "1"), ("hip", "0"), ("rccl", "1")])
+def test_five_ranks_uneven_slabs_three_distributed_levels(mode, replicate, tmp_path):
+    """As many ranks as a one-GPU box admits (its process guard allows six processes on the card: five ranks beside this test
+    runner; the 8-rank run is the driver's): fp32, n = 257, 5 levels, dist_min_n = 65 -- three distributed levels whose
+    coarsest has 64 cells for five ranks (uneven slabs: 12 or 13 coarse cells, 48-53 fine planes), the gathered levels
+    replicated on every rank (all-gather) or kept on rank 0 (gather + scatter, MG_REPLICATE_TAIL=0), over the host transport
+    and over RCCL itself. Five ranks == one rank == the oracle, bit for bit; one process group per case, started once."""
+    from multigrid_prj_amd import capi
+    case, desc, b = _case(tmp_path, 257, 5, 1, cycles=2, dtype=1)
+    desc["dist_min_n"] = 65
+    case["desc"] = desc
+    u, hists, fg = _run_ranks(mode, 5, case, tmp_path, timeout=900, extra_env={"MG_REPLICATE_TAIL": replicate})
+    assert fg == 3
+    sizes = [int(p["nz"]) for p in _run_ranks.last_parts]
+    assert sum(sizes) == 257 and len(set(sizes)) > 1, sizes        # uneven split
+    with capi.Solver(capi.make_desc(**desc)) as s:
+        s.set_rhs(b)
+        for _ in range(case["cycles"]):
+            s.cycle()
+        h1, _ = s.solve(0.0, 2)
+        u1 = s.get_solution()
+    assert np.array_equal(u, u1)
+    u_ref, _ = _oracle(desc, b, case["cycles"])
+    assert np.array_equal(u, u_ref)
+    for h in hists:
+        np.testing.assert_allclose(h, h1, rtol=1e-6)
 
 
 @pytest.mark.gpu

@@ -354,6 +354,56 @@ def test_config4_grid_1025_fp32_fused_operators_bit_exact():
     so.close()
 
 
+def test_config4_as_worded_1025_fp32_seven_level_vcycles_bit_exact():
+    """BASELINE config 4's hierarchy on one GPU: 3-D Poisson 1025^3 fp32, SEVEN levels (1025 ... 17), V(2,2) Jacobi omega = 6/7,
+    full weighting, 17^3 coarse grid iterated to relative residual 0.1 -- two whole cycles against the oracle, all 1.08e9
+    unknowns bit for bit, the coarse solver's sweep counts equal. (What 8 ranks add to it -- slabs and exchanges -- is
+    tests/test_distributed.py's part: k ranks == 1 rank.)"""
+    n = 1025
+    kw = dict(dim=3, n=n, levels=7, dtype=capi.MG_F32, length=1.0, alpha=1.0, cycle=capi.CYCLE_V, nu_pre=2, nu_post=2,
+              smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW,
+              coarse_mode=capi.COARSE_TOL, coarse_tol=0.1, coarse_maxit=2000, outer_pre_gs=0)
+    sg = capi.Solver(capi.make_desc(**kw)); so = po.Solver(po.make_desc(**kw))
+    b = po.fill_rhs_3d(n, 1.0, 1.0, 1).astype(np.float32)
+    with sg:
+        assert [sg.level_shape(l)[0] for l in range(7)] == [1025, 513, 257, 129, 65, 33, 17]
+        sg.set_rhs(b); so.set_rhs(b)
+        del b
+        for _ in range(2):
+            stg = sg.cycle(); sto = so.cycle()
+            assert stg.coarse_iters == sto.coarse_iters
+        ug = sg.get_solution(); uo = so.get_solution()
+        assert np.array_equal(ug, uo)
+        del ug, uo
+        # and it is a multigrid cycle: the residual falls by the headline configuration's factor (0.23 per cycle in fp64)
+        hist, _ = sg.solve(0.0, 2)
+        assert hist[2] < 0.4 * hist[1], hist
+    so.close()
+
+
+@pytest.mark.parametrize("zsm", [capi.SMOOTH_ZEBRA_Y, capi.SMOOTH_ZEBRA_X], ids=["y-lines", "x-lines"])
+def test_config5_as_worded_semi_coarsening_plus_line_smoother_513_bit_exact(zsm):
+    """BASELINE config 5 AS WORDED at full size: anisotropic Poisson 513^3, eps = 0.01 in z, semi-coarsening (the first
+    three transitions coarsen x,y only, 8 levels) AND a zebra line smoother -- lines along y (or x): neither crosses the
+    z-slabs. One V(2,2) cycle on the GPU against one cycle of the oracle, all 1.35e8 unknowns bit for bit, then the
+    reduction factor of further cycles (point smoothers on this hierarchy: 0.21 Jacobi / 0.067 red-black per cycle)."""
+    n = 513
+    kw = dict(dim=3, n=n, levels=8, dtype=capi.MG_F64, length=1.0, alpha=1.0, cycle=capi.CYCLE_V, nu_pre=2, nu_post=2,
+              smoother=zsm, omega=1.0, restriction=capi.RESTRICT_FULLW,
+              coarse_mode=capi.COARSE_FIXED, coarse_maxit=20, outer_pre_gs=0, aniso=(1.0, 1.0, 0.01), semi_xy=3)
+    sg = capi.Solver(capi.make_desc(**kw)); so = po.Solver(po.make_desc(**kw))
+    b = po.fill_rhs_3d(n, 1.0, 1.0, 1)
+    with sg:
+        assert [sg.level_shape(l) for l in (0, 3, 4, 7)] == [(513, 513, 513), (513, 65, 65), (257, 33, 33), (33, 5, 5)]
+        sg.set_rhs(b); so.set_rhs(b)
+        del b
+        sg.cycle(); so.cycle()
+        assert np.array_equal(sg.get_solution(), so.get_solution())
+        hist, _ = sg.solve(0.0, 3)
+        assert hist[-1] / hist[-2] < 0.15, hist
+    so.close()
+
+
 with open(os.path.join(G, "ref_solve.json")) as _f:
     SOLVES = json.load(_f)
 
