@@ -1263,9 +1263,11 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
     const bool prof = profiling_ && l == 0 && mine;
     // launch-bound levels (65^3 and below; rows too narrow for the fused pair): V(2,2) Jacobi with full weighting runs as ONE
     // launch either side of the coarser levels -- J(J(0)) + residual + restriction, and J(J(u + P e)) (mg_small_levels.hip)
+    // levels up to this size take the brick kernels even where the row-wide fused pair would run (MG_SMALL_MAX_N)
+    static const int small_max_n = [] { const char *e = getenv("MG_SMALL_MAX_N"); return e ? atoi(e) : 0; }();
     const bool small = mine && !prof && !stage_fn_ && !lv_[l].dist && lv_[l + 1].present && !lv_[l + 1].dist &&
                        d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre == 2 && d_.nu_post == 2 && d_.restriction == MG_RESTRICT_FULLW &&
-                       !jacobi2_ok<T>(lv_[l].g) && small_fused_ok<T>(lv_[l].g, lv_[l + 1].g);
+                       (!jacobi2_ok<T>(lv_[l].g) || lv_[l].g.nx <= small_max_n) && small_fused_ok<T>(lv_[l].g, lv_[l + 1].g);
     const bool small_pre = small && u_zero;   // the zero guess is part of the fused kernel's contract
     if (small_pre) {
         lv_[l + 1].rhs_halo_ok = false;
