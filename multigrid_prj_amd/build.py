@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmg_hip.so")
 
-SOURCES = ["mg_kernels.hip", "mg_jacobi_fast.hip", "mg_pair_wide.hip", "mg_transfer_fast.hip", "mg_small_levels.hip", "mg_solver.cpp", "mg_dist.cpp", "mg_capi.cpp"]
+SOURCES = ["mg_kernels.hip", "mg_jacobi_fast.hip", "mg_pair_wide.hip", "mg_rr_wide.hip", "mg_transfer_fast.hip", "mg_small_levels.hip", "mg_solver.cpp", "mg_dist.cpp", "mg_capi.cpp"]
 HEADERS = ["mg_geom.h", "mg_kernels.h", "mg_solver.h", "mg_comm.h"]
 # -ffp-contract=off: products and sums round separately, like the reference built for
 # baseline x86-64 -- required for bit parity with the oracle.

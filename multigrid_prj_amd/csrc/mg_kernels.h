@@ -89,6 +89,13 @@ void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, con
 // dup_kc > 0 (gc.nz must be 1): a second single coarse plane dup_kc coarse planes further up (its fine planes start 2 dup_kc
 // further up and there are dup_nzf of them) in the same launch -- the two boundary pieces of a z-slab
 
+// wide-tile form of the same operator (mg_rr_wide.hip): rows of 128 / 256 lanes; launch_resid_restrict_fw hands over to it
+template <typename T> bool rr_wide_ok(const Geom &gf, const Geom &gc);
+template <typename T>
+void launch_rr_wide(hipStream_t s, const Geom &gf, const Geom &gc, const Coef<T> &c, const T *u, const T *rhs, T *coarse,
+                    int dup_kc, int dup_nzf);
+void set_rr_wide(int mode);   // measurement tools only: 0 = never, 1 = wherever the shape allows, -1 = default
+
 // launch-bound levels (65^3 and below), V(2,2) Jacobi, whole 3-D levels (mg_small_levels.hip): the three launches either side
 // of the coarser levels in one each -- u_out = J(J(0)), coarse = R(rhs - A u_out)  /  out = J(J(u + P e))
 template <typename T> bool small_fused_ok(const Geom &gf, const Geom &gc);

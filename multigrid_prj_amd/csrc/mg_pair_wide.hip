@@ -53,7 +53,7 @@ template <> struct WV<float> { static constexpr int V = 4; };
 // One partial sum per workgroup -> partials[blockIdx.x] (fixed order inside the workgroup; k_reduce_final adds them).
 template <typename T, int TPR, int G, bool DAMPED, bool CORR, bool ZEROU, bool RB = false, bool NORM = false>
 __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, const T *__restrict__ u_,
-                                                   const T *__restrict__ rhs_, T *__restrict__ out_, int nby, int nbz,
+                                                   const T *__restrict__ rhs_, T *__restrict__ out_, int nby, int zc,
                                                    const T *__restrict__ coarse, Geom gc, int dup_planes,
                                                    double *__restrict__ partials)
 {
@@ -67,30 +67,53 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
     __shared__ __align__(16) T sv[2][NROW][LP];  // first-sweep planes p-1 (read) / p (written)
     __shared__ double snorm[NORM ? TPR * G / 64 : 1];
 
-    const int nblocks = nby * nbz, ntotal = dup_planes > 0 ? 2 * nblocks : nblocks;
-    const int per = (ntotal + 7) >> 3;
-    int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-aware order
-    if (bid >= ntotal) {                                   // whole workgroup
-        if (NORM && threadIdx.x == 0) partials[blockIdx.x] = 0.;
-        return;
-    }
-    const bool second = bid >= nblocks;
-    if (second) { bid -= nblocks; g.gz0 += dup_planes; }
-    const long long dup_off = second ? (long long)dup_planes * g.plane : 0;
-    const T *__restrict__ u = u_ + dup_off;
-    const T *__restrict__ rhs = rhs_ + dup_off;
-    T *__restrict__ out = out_ + dup_off;
-    const int by = bid % nby, bz = bid / nby;
+    // Work = (copies x) y-tiles x planes, cut into gridDim.x equal RANGES of consecutive planes of consecutive tiles: one
+    // workgroup per CU marches its range, changing tile (new prologue) at most once or twice. Every CU gets the same number of
+    // plane steps (no last round that is two thirds empty: 86 tiles x 11 chunks = 3.7 rounds of 256 before), and a chunk
+    // boundary -- two planes of first-sweep work done twice -- only exists where a range starts.
     const int t = threadIdx.x, lane = t & 63;
     const int grp = __builtin_amdgcn_readfirstlane(t / TPR);  // y-group of this wave: scalar
     const int xt = t - grp * TPR;                             // lane position in the row
     const int x0 = V * xt;                                    // the gate guarantees nx - 1 == TPR * V
     const bool tail = (xt == TPR - 1);                        // last thread of the row: also owns the Dirichlet column nx-1
     const bool tailwave = (xt >> 6) == (TPR >> 6) - 1;
-    const int Y0 = by * S, i0 = grp * R;                      // tile rows Y0 .. Y0+NROW-1; this thread: tile rows i0, i0+1
-    const int ZC = (g.nz + nbz - 1) / nbz;
-    const int z0 = bz * ZC, z1 = min(z0 + ZC, g.nz);
+    const int i0 = grp * R;                                   // this thread: tile rows i0, i0+1
     const bool lo_grp = (grp == 0), hi_grp = (grp == G - 1);  // the groups that also fetch a halo row of u
+    double nsq = 0.;
+    const long long per_copy = (long long)nby * g.nz, total = (dup_planes > 0 ? 2 : 1) * per_copy;
+    const int nwg = (int)gridDim.x, wper = nwg >> 3;          // the launcher makes the grid a multiple of 8
+    const int wi = (blockIdx.x & 7) * wper + (blockIdx.x >> 3);  // XCD-aware order: an XCD takes consecutive ranges
+    // zc == 0: ranges (above). zc > 0: z-chunks of zc planes, item = (copy, chunk, tile) with the tile running fastest, dealt
+    // round-robin: y-neighbouring tiles sit on neighbouring workgroups and march the same planes at the same time, so the halo
+    // rows they share are cache hits. Ranges keep that only when a range is a whole fraction of a tile's column; the launcher
+    // picks (wide_plan).
+    const int nbz = zc > 0 ? (g.nz + zc - 1) / zc : 0;
+    const long long items = (dup_planes > 0 ? 2 : 1) * (long long)nby * nbz;
+    long long w0 = zc > 0 ? wi : total * wi / nwg;
+    const long long w1 = zc > 0 ? items : total * (wi + 1) / nwg;
+    while (w0 < w1) {
+    bool second;
+    int by, z0, z1;
+    if (zc > 0) {
+        const long long per = (long long)nby * nbz;
+        second = w0 >= per;
+        const long long wr = w0 - (second ? per : 0);
+        const int bz = (int)(wr / nby);
+        by = (int)(wr - (long long)bz * nby);
+        z0 = bz * zc; z1 = min(z0 + zc, g.nz);
+        w0 += nwg;
+    } else {
+        second = w0 >= per_copy;
+        const long long wr = w0 - (second ? per_copy : 0);
+        by = (int)(wr / g.nz);
+        z0 = (int)(wr - (long long)by * g.nz); z1 = (int)min((long long)g.nz, z0 + (w1 - w0));
+        w0 += z1 - z0;
+    }
+    const long long dup_off = second ? (long long)dup_planes * g.plane : 0;
+    const T *__restrict__ u = u_ + dup_off;
+    const T *__restrict__ rhs = rhs_ + dup_off;
+    T *__restrict__ out = out_ + dup_off;
+    const int Y0 = by * S;                                    // tile rows Y0 .. Y0+NROW-1
 
     long long urow[R];
     bool ybnd[R], outrow[R];
@@ -108,7 +131,7 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
     const int hs = lo_grp ? 0 : NROW + 1;  // its LDS row
 
     const int zhalo = (g.gnz != g.nz) ? 2 : 1;
-    const int gzo = g.gz0, gzn = g.gnz;
+    const int gzo = g.gz0 + (second ? dup_planes : 0), gzn = g.gnz;   // global z of local plane 0 / global plane count
     auto plane_of = [&](int p) { return (long long)min(max(p, -zhalo), g.nz - 1 + zhalo) * g.plane; };
 
     // ---- on-the-fly prolongation (CORR): coarse rows A = (Y0+i0)/2 under the even row, B = A+1; the odd row is their
@@ -258,8 +281,6 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
         }
         return sq;
     };
-    double nsq = 0.;
-
     vec um[R], uc[R], up[R], vm[R], vc[R], bq[R];
     // ---- prologue: planes z0-2 and z0-1 of u (corrected), plane z0-1 published
     {
@@ -315,7 +336,6 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
     // (all 16 waves of the tile meet at one barrier per plane: without it the CU alternates between waiting and computing).
     vec nu[R], nb[R], nh = (vec)(0);
     T nter[R], nvt[R], nhter = 0;
-    T vtq[R] = {0, 0};   // rhs of the Dirichlet column on plane q (the row's last thread): goes out with the second sweep
     auto fetch = [&](int pu1, int pb) {   // raw u of plane pu1 (rows, halo row, tail column) and rhs of plane pb
         const long long pn = plane_of(pu1), po = plane_of(pb);
 #pragma unroll
@@ -427,7 +447,6 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
                     }
                     __builtin_nontemporal_store(res, (vec *)((out + (qo + urow[r])) + x0));
                     constexpr int LINE = 128 / (int)sizeof(T), TLN = LINE / V;  // lanes that write the tail line
-                    const T vq63 = lane_bcast(vtq[r], 63);   // rhs(q, row, nx-1) in the tail wave: its last thread fetched it one step ago
                     if (tailwave && lane >= 64 - TLN) {
                         // column nx-1 (Dirichlet) as one full 128-byte line: value + zero padding
                         const int j = lane - (64 - TLN);
@@ -436,7 +455,7 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
                         if (xs < line_end) {
                             const long long rb0 = qo + urow[r];
                             vec tv = (vec)(0);
-                            if (j == 0) tv[0] = vq63;
+                            if (j == 0) tv[0] = sv[sl][i][V + TPR * V];   // rhs(q, row, nx-1): the first sweep's value on the Dirichlet column
                             __builtin_nontemporal_store(tv, (vec *)(out + rb0 + xs));
                         }
                     }
@@ -445,8 +464,9 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < R; r++) { um[r] = uc[r]; uc[r] = up[r]; vm[r] = vc[r]; vc[r] = v[r]; bq[r] = b[r]; vtq[r] = vtail[r]; }
+        for (int r = 0; r < R; r++) { um[r] = uc[r]; uc[r] = up[r]; vm[r] = vc[r]; vc[r] = v[r]; bq[r] = b[r]; }
     }
+    }   // next chunk of this workgroup's range
     if (NORM) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nsq += __shfl_down(nsq, off, 64);
@@ -460,22 +480,43 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
     }
 }
 
-// z-chunks per launch: one workgroup per CU, so the launch runs in rounds of 256 workgroups; a chunk of zc planes costs
-// zc + 2 plane steps (+ the prologue). Pick the chunk count whose last round is as full as possible.
-static int wide_nbz(const Geom &g, int nby, int ncopy)
+// How a launch is dealt to the CUs (one workgroup each: 148 KB of LDS): `grid` workgroups (a multiple of 8 for the XCD-aware
+// order) and either RANGES (zc = 0: tile-planes cut into `grid` equal runs -- every CU the same number of plane steps, two extra
+// first-sweep planes only where a run starts) or z-CHUNKS of zc planes dealt round-robin (y-neighbouring tiles march the same
+// planes at the same time and share their halo rows in L2, but the last round of chunks is partly empty). Ranges keep the
+// lockstep only when a run is a whole fraction of a tile's column (513^3 on 256 CUs: 86 tiles x 513 planes / 256 = 172.3 planes
+// = a third of a column; 1025^3 fp32: 685 planes = two thirds of one: 3.46 ms as ranges against 3.07 as chunks).
+struct WidePlan { int grid, zc; };
+static WidePlan wide_plan(const Geom &g, int nby, int ncopy)
 {
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        const char *e = getenv("MG_PW_GRID");
+        return std::max(8, ((e ? atoi(e) : n) / 8) * 8);
+    }();
+    static const int mode = [] { const char *e = getenv("MG_PW_MODE"); return e ? atoi(e) : -1; }();   // 0 ranges, 1 chunks, -1 auto
     static const int zc_env = [] { const char *e = getenv("MG_PW_ZC"); return e ? atoi(e) : 0; }();
-    if (zc_env > 1) return (g.nz + zc_env - 1) / zc_env;
-    int bestk = 1;
+    const long long total = (long long)ncopy * nby * g.nz;
+    const int grid = (int)std::max<long long>(8, (std::min<long long>(ncu, total / 3) / 8) * 8);
+    const double run = (double)total / grid, k = std::max(1.0, std::floor(g.nz / run + 0.5));
+    const bool aligned = std::fabs(k * run - g.nz) <= std::max(2.0, 0.012 * g.nz);
+    // measured on one box, same process (tools/ab_modes.sh, 513^3 fp64, ms per launch ranges / chunks): plain pair 0.661 / 0.654,
+    // folding pair 0.723 / 0.734, whole cycle 2.43 / 2.39 -- whole levels take chunks; a slab piece (a few dozen planes: 86 tiles
+    // x 2 chunks fill two thirds of the chip, x 3 one workgroup more than it) takes ranges: 64 planes 0.111 -> 0.089 ms
+    const bool piece = g.gnz != g.nz;
+    if (mode == 0 || (mode < 0 && zc_env <= 0 && aligned && piece)) return {grid, 0};
+    // chunks: the count whose last round is fullest; a chunk of zc planes costs zc + 2 plane steps + the prologue
+    int best_zc = std::max(1, g.nz);
     double best = 1e30;
-    for (int k = 1; k <= std::max(1, g.nz / 4); k++) {
-        const int zc = (g.nz + k - 1) / k;
-        const int kk = (g.nz + zc - 1) / zc;  // chunks actually launched
-        const double rounds = std::ceil((double)ncopy * nby * kk / 256.0);
+    for (int kk = 1; kk <= std::max(1, g.nz / 4); kk++) {
+        const int zc = (g.nz + kk - 1) / kk, nbz = (g.nz + zc - 1) / zc;
+        const double rounds = std::ceil((double)ncopy * nby * nbz / grid);
         const double cost = std::max(rounds, 1.0) * (zc + 3.5);
-        if (cost < best - 1e-9) { best = cost; bestk = kk; }
+        if (cost < best - 1e-9) { best = cost; best_zc = zc; }
     }
-    return bestk;
+    if (zc_env > 0) best_zc = zc_env;
+    return {grid, best_zc};
 }
 
 int g_wide_mode = -1;
@@ -495,7 +536,7 @@ bool pair_wide_ok(const Geom &g)
     const int tpr = (g.nx - 1) / V;
     if (tpr != 128 && tpr != 256) return false;
     static const int min_rows = [] { const char *e = getenv("MG_PW_MIN_NY"); return e ? atoi(e) : 200; }();
-    return g.ny >= min_rows && g.nz >= 2;
+    return g.ny >= min_rows && g.nz >= 8;   // (thin pieces -- the boundary planes of a slab -- stay with k_jacobi2: 17 against 28 us)
 }
 
 template <typename T>
@@ -507,13 +548,13 @@ int launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T>
     const int G = 1024 / tpr, S = 2 * G - 2;
     const int nby = (g.ny - 1 + S - 1) / S;
     const int ncopy = dup > 0 ? 2 : 1;
-    const int nbz = wide_nbz(g, nby, ncopy);
-    const int grid = ((ncopy * nby * nbz + 7) / 8) * 8;
+    const WidePlan plan = wide_plan(g, nby, ncopy);
+    const int grid = plan.grid, zc = plan.zc;
     const bool damped = (omega != (T)1) && !rb;
 #define MG_PW(TPR, GG, D, C, Z, RBB) \
-    hipLaunchKernelGGL((k_pairw<T, TPR, GG, D, C, Z, RBB>), dim3(grid), dim3(TPR * GG), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, dup, (double *)nullptr)
+    hipLaunchKernelGGL((k_pairw<T, TPR, GG, D, C, Z, RBB>), dim3(grid), dim3(TPR * GG), 0, s, g, c, omega, u, rhs, out, nby, zc, coarse, gc, dup, (double *)nullptr)
 #define MG_PWN(TPR, GG, D) \
-    hipLaunchKernelGGL((k_pairw<T, TPR, GG, D, false, false, false, true>), dim3(grid), dim3(TPR * GG), 0, s, g, c, omega, u, rhs, out, nby, nbz, coarse, gc, dup, d_partials)
+    hipLaunchKernelGGL((k_pairw<T, TPR, GG, D, false, false, false, true>), dim3(grid), dim3(TPR * GG), 0, s, g, c, omega, u, rhs, out, nby, zc, coarse, gc, dup, d_partials)
     const bool norm = d_partials && !rb && !coarse && !zero_u;
 #define MG_PW_SHAPE(TPR, GG) \
     do { \

@@ -431,6 +431,7 @@ template <typename T>
 void launch_resid_restrict_fw(hipStream_t s, const Geom &gf, const Geom &gc, const Coef<T> &c, const T *u,
                               const T *rhs, T *coarse, int dup_kc, int dup_nzf)
 {
+    if (rr_wide_ok<T>(gf, gc)) { launch_rr_wide<T>(s, gf, gc, c, u, rhs, coarse, dup_kc, dup_nzf); return; }
     constexpr int CV = PV<T>::V / 2;
     constexpr int CR = 1;                                     // coarse rows per workgroup (2 measured slower again after the mailbox change: 185 VGPRs, 3.28 vs 3.10 ms per cycle)
     const int ncol = gc.nx - 1;                               // coarse columns owned by lanes

@@ -98,7 +98,7 @@ static int run(int n, int reps, const std::string &what)
     auto ab = [&](const char *name, double npts, double bytes_pt, auto fn) {
         float ms[2] = {0, 0};
         for (int wide = 0; wide < 2; wide++) {
-            set_pair_wide(wide);
+            set_pair_wide(wide); set_rr_wide(wide);
             CK(hipMemsetAsync(F.base[2 + wide], 0x5a, F.elems * sizeof(T), s));
             fn(wide); fn(wide);
             CK(hipStreamSynchronize(s));
@@ -162,7 +162,59 @@ static int run(int n, int reps, const std::string &what)
             ab(nm, sp, 3 * B, [&](int w) { launch_rb_fused<T>(s, gs, c, F.p(0) + off, F.p(1) + off, F.p(2 + w) + off, (const T *)nullptr, gs, 0); });
         }
     }
-    set_pair_wide(-1);
+    if (what == "rr" || what == "all" || what == "whole") {
+        // residual + full weighting: whole level, and a slab's pieces (interior coarse planes, the two boundary planes in one launch)
+        auto cmp_coarse = [&](const char *name, double npts, auto fn) {
+            float ms[2] = {0, 0};
+            T *outc[2];
+            for (int w = 0; w < 2; w++) { CK(hipMalloc(&outc[w], C.elems * sizeof(T))); CK(hipMemset(outc[w], 0x5a, C.elems * sizeof(T))); }
+            for (int wide = 0; wide < 2; wide++) {
+                set_rr_wide(wide);
+                T *pc = outc[wide] + (size_t)C.gh * C.g.plane;
+                fn(pc); fn(pc);
+                CK(hipStreamSynchronize(s));
+                CK(hipGetLastError());
+                CK(hipEventRecord(e0, s));
+                for (int i = 0; i < reps; i++) fn(pc);
+                CK(hipEventRecord(e1, s));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms[wide], e0, e1));
+                ms[wide] /= reps;
+            }
+            CK(hipMemsetAsync(d_bad, 0, 8, s));
+            hipLaunchKernelGGL(k_diff, dim3(2048), dim3(256), 0, s, (const unsigned *)outc[0], (const unsigned *)outc[1], C.elems * sizeof(T) / 4, d_bad);
+            unsigned long long bad = 0;
+            CK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, s));
+            CK(hipStreamSynchronize(s));
+            const double gb = npts * 2.125 * B / 1e9;
+            printf("%-34s k_resid_restrict_fw %8.4f ms (%5.2f TB/s)   k_rrw %8.4f ms (%5.2f TB/s, frac %.3f)   %s\n", name, ms[0], gb / ms[0], ms[1],
+                   gb / ms[1], gb / ms[1] / 8.0, bad ? "MISMATCH" : "bit-equal");
+            if (bad) { printf("   %llu differing 32-bit words\n", bad); fails++; }
+            fflush(stdout);
+            CK(hipFree(outc[0])); CK(hipFree(outc[1]));
+        };
+        cmp_coarse("residual + restriction, whole level", pts, [&](T *pc) { launch_resid_restrict_fw<T>(s, F.g, C.g, c, F.p(0), F.p(1), pc, 0, 0); });
+        for (int nzs : {64, 32}) {
+            const int zs = ((n / 3) / 4) * 4;
+            Geom gs = F.g; gs.nz = nzs; gs.gz0 = zs;
+            Geom gcs = C.g; gcs.nz = nzs / 2; gcs.gz0 = zs / 2;
+            const long long off = (long long)zs * F.g.plane, offc = (long long)(zs / 2) * C.g.plane;
+            char nm[96];
+            snprintf(nm, sizeof nm, "rr slab %d planes: whole", nzs);
+            cmp_coarse(nm, (double)n * n * nzs, [&](T *pc) { launch_resid_restrict_fw<T>(s, gs, gcs, c, F.p(0) + off, F.p(1) + off, pc + offc, 0, 0); });
+            // the pieces of resid_restrict_on_slab_t: interior coarse planes 1 .. nzc-2, then planes 0 and nzc-1 in one launch
+            const int nzc = nzs / 2;
+            Geom gci = gcs; gci.nz = nzc - 2; gci.gz0 = gcs.gz0 + 1;
+            Geom gfi = gs; gfi.nz = 2 * (nzc - 2); gfi.gz0 = gs.gz0 + 2;
+            snprintf(nm, sizeof nm, "rr slab %d planes: interior", nzs);
+            cmp_coarse(nm, (double)n * n * (nzs - 4), [&](T *pc) { launch_resid_restrict_fw<T>(s, gfi, gci, c, F.p(0) + off + 2 * F.g.plane, F.p(1) + off + 2 * F.g.plane, pc + offc + C.g.plane, 0, 0); });
+            Geom gc0 = gcs; gc0.nz = 1;
+            Geom gf0 = gs; gf0.nz = 2;
+            snprintf(nm, sizeof nm, "rr slab %d planes: boundary x2", nzs);
+            cmp_coarse(nm, (double)n * n * 4, [&](T *pc) { launch_resid_restrict_fw<T>(s, gf0, gc0, c, F.p(0) + off, F.p(1) + off, pc + offc, nzc - 1, 2); });
+        }
+    }
+    set_pair_wide(-1); set_rr_wide(-1);
     printf("%s\n", fails ? "FAILED" : "all variants bit-equal");
     return fails;
 }
