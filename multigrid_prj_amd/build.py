@@ -55,25 +55,36 @@ def build(force: bool = False, verbose: bool = False) -> str:
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)
         jobs.append((src, obj, stale))
 
+    # several processes may find the library stale at once (the ranks of bench.py --gpus N, tests/dist_worker.py): temporary
+    # names are per process and the whole build runs under a file lock, so nobody links a half-written object
+    tag = f".tmp{os.getpid()}"
+
     def compile_one(job):
         src, obj, stale = job
         if stale:
-            cmd = [hipcc, *flags, "-c", src, "-o", obj + ".tmp"]
+            cmd = [hipcc, *flags, "-c", src, "-o", obj + tag]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
-            os.replace(obj + ".tmp", obj)
+            os.replace(obj + tag, obj)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
-        objs = list(ex.map(compile_one, jobs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
-    if with_rccl:
-        cmd += ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    import fcntl
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not is_stale():     # somebody else built it while we waited
+            return LIB_PATH
+        jobs = [(src, obj, force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time))
+                for src, obj, _ in jobs]
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            objs = list(ex.map(compile_one, jobs))
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + tag]
+        if with_rccl:
+            cmd += ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        os.replace(LIB_PATH + tag, LIB_PATH)
     return LIB_PATH
 
 

@@ -1595,6 +1595,10 @@ static bool try_launch_coarse_jacobi_rows(hipStream_t s, const Geom &g, const Co
     static const int skip_env = [] { const char *e = getenv("MG_COARSE_SKIP"); return e ? atoi(e) : 8; }();
     int skip = skip_env < 1 ? 1 : skip_env;
     if (3 * total * sizeof(T) > (size_t)150 * 1024) skip = 1;   // no room for the window's first iterate
+    // the windowed norm test equals the reference's test per sweep only while the residual norm cannot dip below the tolerance
+    // and rise again inside a window: guaranteed for 0 < omega <= 1 (damped Jacobi on this operator is a contraction in the
+    // 2-norm), not outside that range -- there every sweep is tested
+    if (!(omega > (T)0 && omega <= (T)1)) skip = 1;
     const size_t bytes = (skip > 1 ? 3 : 2) * total * sizeof(T);
     const int W = g.nx - 2, nseg = (W + SEG - 1) / SEG;
     if (W < SEG || nseg * SEG - W > 1) return false;  // full runs, at most one shared point per row

@@ -1295,7 +1295,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
             launch_inject<T>(stream_, lv_[l].g, stage_g_, ptr<T>(MG_ARR_TMP, l), stageptr<T>(0));
         }
         MG_HIP(hipGetLastError());
-        if (prof) MG_TRY(prof_end(l, MG_PROF_RESID_RESTRICT, 1, 2));
+        if (prof) MG_TRY(prof_end(l, MG_PROF_RESID_RESTRICT, 1, fuse_rr_slab ? 1 : 2));
         MG_TRY(gather_S(MG_ARR_RHS));
         if (lv_[l + 1].present) {
             const bool skip0 = can_skip_zeroing<T>(l + 1) || l + 1 == L - 1;
@@ -1318,7 +1318,7 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         } else {
             MG_TRY(restrict_t<T>(l, d_.restriction, MG_ARR_TMP, MG_ARR_RHS));
         }
-        if (prof) MG_TRY(prof_end(l, MG_PROF_RESID_RESTRICT, 1, fuse_rr ? 1 : 2));
+        if (prof) MG_TRY(prof_end(l, MG_PROF_RESID_RESTRICT, 1, (fuse_rr || fuse_rr_slab) ? 1 : 2));   // the slab-fused form is ONE segment (exchange + interior + boundary launches), like the pair
         const bool skip0 = can_skip_zeroing<T>(l + 1) || l + 1 == L - 1;   // the coarsest-grid solver takes the zero guess as a flag
         if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
         MG_TRY(vcycle_rec_t<T>(l + 1, skip0));

@@ -55,6 +55,9 @@ def test_bench_dry_rank_runs_one_ranks_schedule_on_one_gpu():
     assert "dry_run" in out and "WITHOUT communication" in out["dry_run"]
     assert out["transport"] == "dry-run" and out["rccl_ranks"] is None and out["n_gpus"] == 4
     assert out["comm_per_cycle"]["message_groups"] > 0 and out["ms_per_step"] > 0
+    # every finest-level row is priced per SEGMENT (exchange + interior + boundary launches count as one): one per cycle timed
+    rr = [k for k in out["kernels"] if "residual" in k["kernel"]]
+    assert rr and all(k["launches_timed"] == 3 for k in rr), out["kernels"]
 
 
 @pytest.mark.gpu
