@@ -502,10 +502,13 @@ static WidePlan wide_plan(const Geom &g, int nby, int ncopy)
     const double run = (double)total / grid, k = std::max(1.0, std::floor(g.nz / run + 0.5));
     const bool aligned = std::fabs(k * run - g.nz) <= std::max(2.0, 0.012 * g.nz);
     // measured on one box, same process (tools/ab_modes.sh, 513^3 fp64, ms per launch ranges / chunks): plain pair 0.661 / 0.654,
-    // folding pair 0.723 / 0.734, whole cycle 2.43 / 2.39 -- whole levels take chunks; a slab piece (a few dozen planes: 86 tiles
-    // x 2 chunks fill two thirds of the chip, x 3 one workgroup more than it) takes ranges: 64 planes 0.111 -> 0.089 ms
-    const bool piece = g.gnz != g.nz;
-    if (mode == 0 || (mode < 0 && zc_env <= 0 && aligned && piece)) return {grid, 0};
+    // folding pair 0.723 / 0.734, whole cycle 2.43 / 2.39; a slab piece alone on the chip (64 planes: 86 tiles x 2 chunks fill two
+    // thirds of it, x 3 one workgroup more than it): 0.111 ms as chunks, 0.089 as ranges. Chunks are nevertheless the default
+    // everywhere: a grid of exactly one workgroup per CU, each holding its CU for the whole launch, takes TWICE as long as soon
+    // as anything else holds a CU -- RCCL's send / recv kernels, the boundary launch on the communication stream -- while
+    // one-chunk workgroups are dispatched to whatever CUs are free. Ranges: MG_PW_MODE=0 (measurements on an otherwise idle GPU).
+    (void)aligned;
+    if (mode == 0) return {grid, 0};
     // chunks: the count whose last round is fullest; a chunk of zc planes costs zc + 2 plane steps + the prologue
     int best_zc = std::max(1, g.nz);
     double best = 1e30;
@@ -516,7 +519,9 @@ static WidePlan wide_plan(const Geom &g, int nby, int ncopy)
         if (cost < best - 1e-9) { best = cost; best_zc = zc; }
     }
     if (zc_env > 0) best_zc = zc_env;
-    return {grid, best_zc};
+    // one workgroup per chunk (the kernel's loop then runs once): the hardware dispatcher deals them
+    const long long items = (long long)ncopy * nby * ((g.nz + best_zc - 1) / best_zc);
+    return {(int)(((items + 7) / 8) * 8), best_zc};
 }
 
 int g_wide_mode = -1;

@@ -297,7 +297,8 @@ static RRPlan rr_wide_plan(const Geom &gc, int nby, int ncopy, bool semi)
     const int grid = (int)std::max<long long>(8, (std::min<long long>(ncu, total / 2) / 8) * 8);
     const double run = (double)total / grid, k = std::max(1.0, std::floor(gc.nz / run + 0.5));
     const bool aligned = std::fabs(k * run - gc.nz) <= std::max(1.0, 0.012 * gc.nz);
-    if (mode == 0 || (mode < 0 && zcc_env <= 0 && aligned && piece)) return {grid, 0};   // whole level: chunks, 0.525 against 0.543 ms at 513^3
+    (void)aligned; (void)piece;
+    if (mode == 0) return {grid, 0};   // ranges only on request (mg_pair_wide.hip: wide_plan says why); whole level 0.543 against 0.525 ms as chunks
     int best_zcc = std::max(1, gc.nz);
     double best = 1e30;
     for (int kk = 1; kk <= gc.nz; kk++) {
@@ -307,7 +308,8 @@ static RRPlan rr_wide_plan(const Geom &gc, int nby, int ncopy, bool semi)
         if (cost < best - 1e-9) { best = cost; best_zcc = zcc; }
     }
     if (zcc_env > 0) best_zcc = zcc_env;
-    return {grid, best_zcc};
+    const long long items = (long long)ncopy * nby * ((gc.nz + best_zcc - 1) / best_zcc);   // one workgroup per chunk
+    return {(int)(((items + 7) / 8) * 8), best_zcc};
 }
 
 int g_rr_wide_mode = -1;
