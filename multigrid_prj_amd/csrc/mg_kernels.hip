@@ -1052,6 +1052,176 @@ __global__ __launch_bounds__(CoarseRowsThreads<SEG>::value) void k_coarse_jacobi
     }
 }
 
+// ---------------------------------------------------------------- LDS coarse solver, red-black GS
+// Solver::Solve (solvers.hpp:324-342) with the red-black smoother (BASELINE config 3's coarse solve: ~60 sweeps of 17^3 per
+// cycle) on the row-segment layout of k_coarse_jacobi_rows: a thread owns a run of SEG interior points of one row, own values
+// and right-hand sides in registers, ONE LDS copy of the iterate (the sweep is in place). A sweep is two colour phases -- every
+// thread evaluates all its points and keeps those of the phase's colour ((x + y + z) & 1): the others' inputs are mid-update
+// and their values are dropped -- and the residual pass, three barriers in all, where the generic loop (k_coarse_solve_lds)
+// re-derives every point's indices in each of its passes (7.6 us per sweep; this one ~3). Same point_update / residual
+// expressions => the iterate is bit-identical after the same number of sweeps (tests/test_gpu_parity.py::test_coarse_solver).
+template <typename T, int DIM, int SEG>
+__global__ __launch_bounds__(CoarseRowsThreads<SEG>::value) void k_coarse_rb_rows(Geom g, Coef<T> c, T *x, const T *rhs, int maxit,
+                                                                                  double tol, int fixed, CoarseOut *out)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ double part[2][SWG / 64];
+    const int nx = g.nx, ny = g.ny, npl = nx * ny, total = npl * g.nz;
+    T *cur = reinterpret_cast<T *>(smem_raw);
+    const int W = nx - 2, nseg = (W + SEG - 1) / SEG;
+    const int irows = (ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
+    const int nthr = (int)blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;
+    const bool active = tid < nseg * irows;
+    const int seg = active ? tid / irows : 0, row = active ? tid - seg * irows : 0;
+    const int z = (DIM == 3) ? 1 + row / (ny - 2) : 0;
+    const int y = 1 + ((DIM == 3) ? row % (ny - 2) : row);
+    const int xs = min(seg * SEG, W - SEG);
+    const bool dup0 = (xs != seg * SEG);  // own point 0 is also the previous run's last point (both owners store the same bits)
+    const int x0 = 1 + xs;
+    const int i0 = (z * ny + y) * nx + x0;
+    const int p0 = (x0 + y + z) & 1;      // colour of own point 0
+    auto dense_to_global = [&](int q) -> long long {
+        const int zz = q / npl, rem = q - zz * npl, yy = rem / nx, xx = rem - yy * nx;
+        return lidx(g, zz, yy, xx);
+    };
+    // -1: interior node, else the colour of the Dirichlet node
+    auto bnd_colour = [&](int q) -> int {
+        const int zz = q / npl, rem = q - zz * npl, yy = rem / nx, xx = rem - yy * nx;
+        const bool b = xx == 0 || xx == nx - 1 || yy == 0 || yy == ny - 1 || (DIM == 3 && (zz == 0 || zz == g.nz - 1));
+        return b ? ((xx + yy + zz) & 1) : -1;
+    };
+    double sqb = 0.;
+    for (int q = tid; q < total; q += nthr) {
+        const long long gi = dense_to_global(q);
+        cur[q] = x[gi];
+        const double t = (double)rhs[gi];
+        sqb += t * t;
+    }
+    T xv[SEG], bv[SEG];
+#pragma unroll
+    for (int k = 0; k < SEG; k++) {
+        xv[k] = 0; bv[k] = 0;
+        if (active) {
+            const long long gi = lidx(g, z, y, x0 + k);
+            xv[k] = x[gi]; bv[k] = rhs[gi];
+        }
+    }
+    int parity = 0;
+    auto block_sum = [&](double v) -> double {  // one barrier; also publishes the LDS stores made before it
+        v = wave_sum_dpp(v);
+        if (lane == 0) part[parity][wv] = v;
+        __syncthreads();
+        double sum = 0;
+        for (int w = 0; w < nw; w++) sum += part[parity][w];
+        parity ^= 1;
+        return sum;
+    };
+    const double nb = block_sum(sqb);
+    const double t2 = tol * tol * nb;
+    const bool pretest = (tol > 0) && (t2 > 1e-290) && (t2 < 1e290);
+    const double t2_hi = t2 * (1. + 1e-9), t2_lo = t2 * (1. - 1e-9);
+    auto above_tol = [&](double nr) -> bool {
+        if (pretest) {
+            if (nr > t2_hi) return true;
+            if (nr < t2_lo) return false;
+        }
+        return sqrt(nr / nb) > tol;  // NaN (zero rhs) compares false, like the reference
+    };
+    // sum r^2 of the current iterate; with_bnd: the Dirichlet nodes still hold the initial guess (before the first sweep:
+    // r = b - 1 * x; after it x == b there and r == b - 1 * b == 0 exactly)
+    auto residual = [&](bool with_bnd) -> double {
+        double sq = 0.;
+        if (with_bnd) {
+            for (int q = tid; q < total; q += nthr) {
+                if (bnd_colour(q) >= 0) {
+                    const T res = rhs[dense_to_global(q)] - (T)1 * cur[q];
+                    sq += (double)res * (double)res;
+                }
+            }
+        }
+        if (active) {
+            const T el = cur[i0 - 1], er = cur[i0 + SEG];
+#pragma unroll
+            for (int k = 0; k < SEG; k++) {
+                const T left = (k == 0) ? el : xv[k > 0 ? k - 1 : 0];
+                const T right = (k == SEG - 1) ? er : xv[k < SEG - 1 ? k + 1 : 0];
+                T fs = 0;  // residual row, diagonal included (solvers.hpp:269-271)
+                if (DIM == 3) fs += c.cz * cur[i0 + k - npl];
+                fs += c.cy * cur[i0 + k - nx];
+                fs += c.cx * left;
+                fs += c.cd * xv[k];
+                fs += c.cx * right;
+                fs += c.cy * cur[i0 + k + nx];
+                if (DIM == 3) fs += c.cz * cur[i0 + k + npl];
+                const T res = bv[k] - fs;
+                const double r2 = (double)res * (double)res;
+                sq += (k == 0 && dup0) ? 0. : r2;
+            }
+        }
+        return block_sum(sq);
+    };
+    auto half_sweep = [&](int colour, bool first) {
+        if (first) {   // the Dirichlet nodes of this colour: x <- b (point_update on a boundary node)
+            for (int q = tid; q < total; q += nthr)
+                if (bnd_colour(q) == colour) cur[q] = rhs[dense_to_global(q)];
+        }
+        if (active) {
+            const T el = cur[i0 - 1], er = cur[i0 + SEG];
+            T num[SEG], quo[SEG];
+#pragma unroll
+            for (int k = 0; k < SEG; k++) {
+                const T left = (k == 0) ? el : xv[k > 0 ? k - 1 : 0];
+                const T right = (k == SEG - 1) ? er : xv[k < SEG - 1 ? k + 1 : 0];
+                T os = 0;
+                if (DIM == 3) os += c.cz * cur[i0 + k - npl];
+                os += c.cy * cur[i0 + k - nx];
+                os += c.cx * left;
+                os += c.cx * right;
+                os += c.cy * cur[i0 + k + nx];
+                if (DIM == 3) os += c.cz * cur[i0 + k + npl];
+                num[k] = bv[k] - os;
+            }
+            div_cd_n<T, SEG>(num, quo, c);
+#pragma unroll
+            for (int k = 0; k < SEG; k++) {
+                if (((p0 + k) & 1) == colour) { xv[k] = quo[k]; cur[i0 + k] = quo[k]; }
+            }
+        }
+        __syncthreads();
+    };
+    int iters = 0, flag = 0;
+    double nr;
+    auto sweep = [&]() { half_sweep(0, iters == 0); half_sweep(1, iters == 0); };
+    if (fixed) {
+        for (int s = 0; s < maxit; s++) { sweep(); iters++; }
+        nr = residual(iters == 0);
+    } else {
+        int counter = maxit;
+        nr = residual(true);
+        while (above_tol(nr)) {
+            if (counter > 0) {
+                sweep();
+                counter -= 1;
+                iters++;
+                nr = residual(false);
+            } else {
+                flag = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < total; q += nthr) x[dense_to_global(q)] = cur[q];
+    if (tid == 0) {
+        out->iters = iters;
+        out->flag = flag;
+        out->relres = sqrt(nr / nb);
+        out->sumsq_rhs = nb;
+        out->sumsq_r = nr;
+    }
+}
+
 // ---------------------------------------------------------------- LDS coarse solver, lexicographic GS (2-D)
 // Solver::Solve with the Gauss-Seidel smoother (the reference's default, -smt 0) on the coarsest
 // grid: iterate and right-hand side in LDS; the sweep is the anti-diagonal wavefront with one
@@ -1644,6 +1814,43 @@ static bool try_launch_coarse_jacobi(hipStream_t s, const Geom &g, const Coef<T>
     }
 }
 
+template <typename T, int DIM, int SEG>
+static bool try_launch_coarse_rb_rows(hipStream_t s, const Geom &g, const Coef<T> &c, T *x, const T *rhs, int maxit, double tol,
+                                      int fixed, CoarseOut *d_out)
+{
+    const size_t total = (size_t)g.nx * g.ny * g.nz, bytes = total * sizeof(T);
+    const int W = g.nx - 2, nseg = (W + SEG - 1) / SEG;
+    if (W < SEG || nseg * SEG - W > 1) return false;  // full runs, at most one shared point per row
+    const int threads = nseg * (g.ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
+    if (threads < 128 || threads > CoarseRowsThreads<SEG>::value || bytes > (size_t)150 * 1024) return false;
+    auto kern = k_coarse_rb_rows<T, DIM, SEG>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                150 * 1024) != hipSuccess) return false;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(((threads + 63) / 64) * 64), bytes, s, g, c, x, rhs, maxit, tol, fixed, d_out);
+    return true;
+}
+
+// red-black coarse solve on the row-segment layout (MG_COARSE_RB_ROWS=0: the generic LDS kernel)
+template <typename T, int DIM>
+static bool try_launch_coarse_rb(hipStream_t s, const Geom &g, const Coef<T> &c, T *x, const T *rhs, int maxit, double tol,
+                                 int fixed, CoarseOut *d_out)
+{
+    static const bool enabled = [] { const char *e = getenv("MG_COARSE_RB_ROWS"); return !(e && e[0] == '0'); }();
+    if (!enabled || g.ny < 3 || (DIM == 3 && g.nz < 3)) return false;
+    const int W = g.nx - 2, irows = (g.ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
+    for (int seg : {5, 4}) {   // (runs of 7 / 8 points: the colour selects went through scratch memory; not instantiated)
+        const int nseg = (W + seg - 1) / seg, threads = nseg * irows;
+        if (W < seg || nseg * seg - W > 1 || threads < 128 || threads > SWG) continue;
+        if (seg == 5) return try_launch_coarse_rb_rows<T, DIM, 5>(s, g, c, x, rhs, maxit, tol, fixed, d_out);
+        return try_launch_coarse_rb_rows<T, DIM, 4>(s, g, c, x, rhs, maxit, tol, fixed, d_out);
+    }
+    return false;
+}
+
 template <typename T>
 static bool try_launch_coarse_gs_rows2d(hipStream_t s, const Geom &g, const Coef<T> &c, T *x, const T *rhs, int maxit,
                                         double tol, int fixed, CoarseOut *d_out)
@@ -1680,6 +1887,10 @@ void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega
                        : try_launch_coarse_jacobi<T, 2>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, 0)) return;
     }
     if (smoother == 0 && try_launch_coarse_gs_rows2d<T>(s, g, c, x, rhs, maxit, tol, fixed, d_out)) return;
+    if (smoother == 2 && g.gz0 == 0 && g.gnz == g.nz) {  // red-black: the row-segment kernel
+        if (g.dim == 3 ? try_launch_coarse_rb<T, 3>(s, g, c, x, rhs, maxit, tol, fixed, d_out)
+                       : try_launch_coarse_rb<T, 2>(s, g, c, x, rhs, maxit, tol, fixed, d_out)) return;
+    }
     if (g.dim == 3) {
         if (try_launch_coarse_lds<T, 3, 5>(s, g, c, omega, smoother, x, rhs, maxit, tol, fixed, d_out)) return;
         hipLaunchKernelGGL((k_coarse_solve<T, 3>), dim3(1), dim3(SWG), 0, s, g, c, omega, smoother, x,
