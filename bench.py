@@ -373,7 +373,7 @@ def main():
         priced("SMOOTH_PROLONG", f"post-smoothing launch that also applies the coarse correction ({pair_kernel}, CORR)",
                sweep_bytes + esz * pts_c, 2 * sweep_bytes + 2 * esz * pts_local + esz * pts_c, "corr"),
         # R(rhs - A u): reads u and rhs, writes the coarse right-hand side
-        priced("RESID_RESTRICT", "finest-level residual + full-weighting restriction (k_resid_restrict_fw)",
+        priced("RESID_RESTRICT", f"finest-level residual + full-weighting restriction ({'k_rrw (wide tiles, mg_rr_wide.hip)' if wide else 'k_resid_restrict_fw'})",
                2 * esz * pts_local + esz * pts_c, 3 * esz * pts_local + esz * (pts_local + pts_c), "rr"),
         priced("PROLONG", "separate prolongation into the finest level", 2 * esz * pts_local + esz * pts_c,
                2 * esz * pts_local + esz * pts_c, "prolong"),
@@ -493,10 +493,16 @@ def profiled_traffic(a):
                 key = "pair" if "pair" not in best or int(r["grid_threads"]) > int(best["pair"]["grid_threads"]) else None
             elif r["kernel"].startswith("k_sweep3d<") and t[:2] == [T, "0"] and t[-1] == "false":
                 key = "single"
+            elif r["kernel"].startswith("k_rrw<") and t[:2] == [T, lanes]:      # <T, TPR, G, SEMI>: the wide-tile residual + restriction
+                key = "rr"
             elif r["kernel"].startswith("k_resid_restrict_fw<") and t[:1] == [T]:
                 key = "rr"
             elif r["kernel"].startswith("k_prolong3d_fast<") and t[:1] == [T]:
                 key = "prolong"
+            if key == "rr" and "rr" in best and best["rr"]["kernel"].startswith("k_rrw<") != r["kernel"].startswith("k_rrw<"):
+                if r["kernel"].startswith("k_rrw<"):
+                    best["rr"] = r        # the wide-tile kernel is the finest level's; the other one only runs below it
+                continue
             if key and (key not in best or int(r["grid_threads"]) > int(best[key]["grid_threads"])):
                 best[key] = r
         for key, r in best.items():   # later rounds' files win
