@@ -354,6 +354,42 @@ def test_config4_grid_1025_fp32_fused_operators_bit_exact():
     so.close()
 
 
+_RANGES_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from multigrid_prj_amd import capi
+from oracle import pyoracle as po
+n, dtype = int(sys.argv[2]), int(sys.argv[3])
+kw = dict(dim=3, n=n, levels=4, dtype=dtype, length=1.0, alpha=1.0, cycle=capi.CYCLE_V, nu_pre=2, nu_post=2,
+          smoother=int(sys.argv[4]), omega=6 / 7 if int(sys.argv[4]) == capi.SMOOTH_JACOBI else 1.0, restriction=capi.RESTRICT_FULLW,
+          coarse_mode=capi.COARSE_FIXED, coarse_maxit=20, outer_pre_gs=0)
+b = po.fill_rhs_3d(n, 1.0, 1.0, 1)
+if dtype == capi.MG_F32:
+    b = b.astype(np.float32)
+sg = capi.Solver(capi.make_desc(**kw)); so = po.Solver(po.make_desc(**kw))
+with sg:
+    sg.set_rhs(b); so.set_rhs(b)
+    for _ in range(2):
+        sg.cycle(); so.cycle()
+    assert np.array_equal(sg.get_solution(), so.get_solution())
+print("ranges ok")
+"""
+
+
+@pytest.mark.parametrize("n,dtype,smoother", [(257, capi.MG_F64, capi.SMOOTH_JACOBI), (513, capi.MG_F32, capi.SMOOTH_RBGS)])
+def test_wide_tile_kernels_dealt_as_balanced_ranges_keep_the_bits(n, dtype, smoother):
+    """The wide-tile kernels (k_pairw, k_rrw) can deal their work as balanced plane RANGES instead of z-chunks (MG_PW_MODE=0,
+    MG_RRW_MODE=0: a workgroup then changes tile in mid-launch and chunk boundaries fall anywhere). The switch is read once per
+    process, so a child process runs two V(2,2) cycles that way against the oracle, bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, MG_PW_MODE="0", MG_RRW_MODE="0")
+    p = subprocess.run([sys.executable, "-c", _RANGES_SCRIPT, root, str(n), str(dtype), str(smoother)], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ranges ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_config4_as_worded_1025_fp32_seven_level_vcycles_bit_exact():
     """BASELINE config 4's hierarchy on one GPU: 3-D Poisson 1025^3 fp32, SEVEN levels (1025 ... 17), V(2,2) Jacobi omega = 6/7,
     full weighting, 17^3 coarse grid iterated to relative residual 0.1 -- two whole cycles against the oracle, all 1.08e9
