@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "mg_kernels.h"
 
@@ -180,6 +182,7 @@ Solver::~Solver()
     for (auto &e : prof_ev_) (void)hipEventDestroy(e);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
+    for (hipEvent_t e : ev_stage_) if (e) (void)hipEventDestroy(e);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -196,6 +199,7 @@ int Solver::init()
     MG_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     MG_HIP(hipEventCreate(&ev0_));
     MG_HIP(hipEventCreate(&ev1_));
+    for (hipEvent_t &e : ev_stage_) MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (nranks_ > 1) {
         // the communication stream outranks the main one: the exchange kernels and the boundary pieces behind them are
         // dispatched ahead of the interior launch they run beside (MG_COMM_PRIORITY=0: same priority)
@@ -340,6 +344,37 @@ T *Solver::ptr(int which, int level) const
 // go through a pinned staging buffer in whole padded planes: one contiguous DMA per chunk and the row
 // (un)packing on the host. hipMemcpy2DAsync from pageable memory took 5 ms for a 257^2 array (0.1 GB/s),
 // a third of the whole solve of the reference's own case.
+// Round 3: the staging buffer has two halves and the row (un)packing runs on a few host threads, so the DMA of one chunk
+// overlaps the packing of the next (1.08 GB at 513^3: 16-19 GB/s up and 8-10 GB/s down before, when chunk k's packing, its DMA
+// and the wait for it ran one after the other on one thread).
+namespace {
+// fn(first_row, last_row) over [0, nrows) on up to `nthreads` threads (the calling thread takes the first share)
+template <typename F>
+void parallel_rows(size_t nrows, int nthreads, F &&fn)
+{
+    nthreads = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthreads, nrows / 64));
+    if (nthreads == 1) { fn((size_t)0, nrows); return; }
+    std::vector<std::thread> th;
+    const size_t per = (nrows + nthreads - 1) / nthreads;
+    for (int t = 1; t < nthreads; t++) {
+        const size_t lo = std::min(nrows, t * per), hi = std::min(nrows, lo + per);
+        if (lo < hi) th.emplace_back([&fn, lo, hi] { fn(lo, hi); });
+    }
+    fn((size_t)0, std::min(nrows, per));
+    for (auto &t : th) t.join();
+}
+int stage_threads()
+{
+    static const int n = [] {
+        const char *e = getenv("MG_STAGE_THREADS");
+        if (e) return std::max(1, atoi(e));
+        const unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(8u, hc ? hc / 2 : 4u));
+    }();
+    return n;
+}
+}  // namespace
+
 int Solver::stage_rows(int which, int level, void *host, bool to_device)
 {
     pair_on_comm_level_ = -1;
@@ -347,38 +382,59 @@ int Solver::stage_rows(int which, int level, void *host, bool to_device)
     const Level &L = lv_[level];
     const size_t es = esize(), row = (size_t)L.g.nx * es, prow = (size_t)L.g.pitch * es;
     const size_t pbytes = (size_t)L.g.plane * es;
-    if (!h_stage_) {
-        h_stage_bytes_ = (size_t)32 << 20;
+    const size_t want = std::max<size_t>((size_t)64 << 20, 2 * pbytes);   // two halves, each at least one plane
+    if (!h_stage_ || h_stage_bytes_ < want) {
+        if (h_stage_) { (void)hipHostFree(h_stage_); h_stage_ = nullptr; }
+        h_stage_bytes_ = want;
         MG_HIP(hipHostMalloc(&h_stage_, h_stage_bytes_));
     }
-    if (pbytes > h_stage_bytes_) {  // a single plane larger than the buffer (n > 2000): grow it
-        (void)hipHostFree(h_stage_); h_stage_ = nullptr;
-        h_stage_bytes_ = pbytes;
-        MG_HIP(hipHostMalloc(&h_stage_, h_stage_bytes_));
-    }
-    const int per = (int)std::max<size_t>(1, h_stage_bytes_ / pbytes);  // planes per chunk
+    const size_t half = h_stage_bytes_ / 2;
+    const int per = (int)std::max<size_t>(1, half / pbytes);  // planes per chunk
     char *dev = reinterpret_cast<char *>(L.base[which]) + (size_t)L.gh * pbytes;      // local plane 0
     if (to_device && which == MG_ARR_RHS) lv_[level].rhs_halo_ok = false;
-    char *st = reinterpret_cast<char *>(h_stage_);
     char *hp = reinterpret_cast<char *>(host);
-    for (int z0 = 0; z0 < L.g.nz; z0 += per) {
-        const int nzc = std::min(per, L.g.nz - z0);
-        if (to_device) {
-            // padding columns stay zero: the staging rows are written whole
-            for (int z = 0; z < nzc; z++)
-                for (int y = 0; y < L.g.ny; y++) {
-                    char *d = st + (size_t)z * pbytes + (size_t)y * prow;
-                    std::memcpy(d, hp + ((size_t)(z0 + z) * L.g.ny + y) * row, row);
-                    std::memset(d + row, 0, prow - row);
-                }
-            MG_HIP(hipMemcpyAsync(dev + (size_t)z0 * pbytes, st, (size_t)nzc * pbytes, hipMemcpyHostToDevice, stream_));
-            MG_HIP(hipStreamSynchronize(stream_));
-        } else {
-            MG_HIP(hipMemcpyAsync(st, dev + (size_t)z0 * pbytes, (size_t)nzc * pbytes, hipMemcpyDeviceToHost, stream_));
-            MG_HIP(hipStreamSynchronize(stream_));
-            for (int z = 0; z < nzc; z++)
-                for (int y = 0; y < L.g.ny; y++)
-                    std::memcpy(hp + ((size_t)(z0 + z) * L.g.ny + y) * row, st + (size_t)z * pbytes + (size_t)y * prow, row);
+    const int ny = L.g.ny, nthr = stage_threads();
+    const int nchunks = (L.g.nz + per - 1) / per;
+    auto half_ptr = [&](int k) { return reinterpret_cast<char *>(h_stage_) + (size_t)(k & 1) * half; };
+    auto pack = [&](int k) {        // host rows of chunk k -> its staging half, padding columns zeroed
+        const int z0 = k * per, nzc = std::min(per, L.g.nz - z0);
+        char *st = half_ptr(k);
+        parallel_rows((size_t)nzc * ny, nthr, [&](size_t lo, size_t hi) {
+            for (size_t r = lo; r < hi; r++) {
+                char *d = st + r * prow;      // plane pitch == ny * row pitch: the rows of a chunk are equally spaced
+                std::memcpy(d, hp + ((size_t)z0 * ny + r) * row, row);
+                std::memset(d + row, 0, prow - row);
+            }
+        });
+    };
+    auto unpack = [&](int k) {
+        const int z0 = k * per, nzc = std::min(per, L.g.nz - z0);
+        const char *st = half_ptr(k);
+        parallel_rows((size_t)nzc * ny, nthr, [&](size_t lo, size_t hi) {
+            for (size_t r = lo; r < hi; r++) std::memcpy(hp + ((size_t)z0 * ny + r) * row, st + r * prow, row);
+        });
+    };
+    auto dma = [&](int k) -> int {
+        const int z0 = k * per, nzc = std::min(per, L.g.nz - z0);
+        if (to_device) MG_HIP(hipMemcpyAsync(dev + (size_t)z0 * pbytes, half_ptr(k), (size_t)nzc * pbytes, hipMemcpyHostToDevice, stream_));
+        else MG_HIP(hipMemcpyAsync(half_ptr(k), dev + (size_t)z0 * pbytes, (size_t)nzc * pbytes, hipMemcpyDeviceToHost, stream_));
+        MG_HIP(hipEventRecord(ev_stage_[k & 1], stream_));
+        return MG_OK;
+    };
+    auto wait_half = [&](int k) -> int { MG_HIP(hipEventSynchronize(ev_stage_[k & 1])); return MG_OK; };
+    if (to_device) {
+        for (int k = 0; k < nchunks; k++) {
+            if (k >= 2) { int rc = wait_half(k); if (rc) return rc; }   // the half's previous DMA has read it
+            pack(k);
+            int rc = dma(k); if (rc) return rc;
+        }
+        MG_HIP(hipStreamSynchronize(stream_));
+    } else {
+        { int rc = dma(0); if (rc) return rc; }
+        for (int k = 0; k < nchunks; k++) {
+            if (k + 1 < nchunks) { int rc = dma(k + 1); if (rc) return rc; }   // the other half: unpacked two chunks ago
+            int rc = wait_half(k); if (rc) return rc;
+            unpack(k);
         }
     }
     return MG_OK;

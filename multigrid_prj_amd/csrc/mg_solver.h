@@ -146,6 +146,7 @@ private:
     int device_;
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    hipEvent_t ev_stage_[2] = {nullptr, nullptr};   // one per half of the host staging buffer (stage_rows)
     std::vector<Level> lv_;
     double *d_partials_ = nullptr;  // per-block partial sums
     double *d_scal_ = nullptr;      // [0] sum r^2, [1] sum b^2, [2] cycle's fine sum r^2
