@@ -393,7 +393,8 @@ int Solver::stage_rows(int which, int level, void *host, bool to_device)
     char *dev = reinterpret_cast<char *>(L.base[which]) + (size_t)L.gh * pbytes;      // local plane 0
     if (to_device && which == MG_ARR_RHS) lv_[level].rhs_halo_ok = false;
     char *hp = reinterpret_cast<char *>(host);
-    const int ny = L.g.ny, nthr = stage_threads();
+    // (threads only where there is something to share: a 257^2 array is 0.5 MB, a thread costs ~30 us to start)
+    const int ny = L.g.ny, nthr = (pbytes * (size_t)std::min(per, L.g.nz) >= ((size_t)8 << 20)) ? stage_threads() : 1;
     const int nchunks = (L.g.nz + per - 1) / per;
     auto half_ptr = [&](int k) { return reinterpret_cast<char *>(h_stage_) + (size_t)(k & 1) * half; };
     auto pack = [&](int k) {        // host rows of chunk k -> its staging half, padding columns zeroed
