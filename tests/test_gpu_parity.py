@@ -354,6 +354,22 @@ def test_config4_grid_1025_fp32_fused_operators_bit_exact():
     so.close()
 
 
+@pytest.mark.parametrize("n,dtype", [(513, "f64"), (513, "f32")])
+def test_wide_tile_kernels_equal_the_row_column_kernels_on_every_piece_geometry(n, dtype):
+    """tools/pairbench (built by __graft_entry__.build()): every variant of the wide-tile kernels -- plain / zero-guess /
+    prolongation-folding Jacobi pairs, one-pass red-black sweeps, residual + full weighting -- on a whole level and on the
+    pieces of a z-slab (whole slab, interior planes, the two boundary pieces in one launch; 64 and 32 planes, coarse planes
+    addressed by global index) through the product's launchers, against the round-2 kernels that the parity tests pinned to
+    the oracle: every 32-bit word of the output arrays, ghost planes and padding included."""
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    exe = os.path.join(root, "tools", "pairbench")
+    if not os.path.exists(exe):
+        pytest.skip("tools/pairbench not built (python __graft_entry__.py build)")
+    p = subprocess.run([exe, str(n), "2", dtype, "all"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0 and "all variants bit-equal" in p.stdout and "MISMATCH" not in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
 _RANGES_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
