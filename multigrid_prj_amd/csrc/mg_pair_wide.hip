@@ -67,10 +67,12 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
     __shared__ __align__(16) T sv[2][NROW][LP];  // first-sweep planes p-1 (read) / p (written)
     __shared__ double snorm[NORM ? TPR * G / 64 : 1];
 
-    // Work = (copies x) y-tiles x planes, cut into gridDim.x equal RANGES of consecutive planes of consecutive tiles: one
-    // workgroup per CU marches its range, changing tile (new prologue) at most once or twice. Every CU gets the same number of
-    // plane steps (no last round that is two thirds empty: 86 tiles x 11 chunks = 3.7 rounds of 256 before), and a chunk
-    // boundary -- two planes of first-sweep work done twice -- only exists where a range starts.
+    // Work = (copies x) y-tiles x planes. Two ways of dealing it (the launcher's wide_plan picks; zc > 0 is the default):
+    //  * zc > 0: z-CHUNKS of zc planes, item = (copy, chunk, tile) with the tile running fastest; workgroup wi takes items wi,
+    //    wi + gridDim.x, ... -- with one workgroup per item (the default grid) the loop below runs once;
+    //  * zc == 0: the tile-planes are cut into gridDim.x equal RANGES of consecutive planes of consecutive tiles: a workgroup
+    //    marches its range, changing tile (new prologue) at most once or twice; every workgroup gets the same number of plane
+    //    steps and a chunk boundary -- two planes of first-sweep work done twice -- only exists where a range starts.
     const int t = threadIdx.x, lane = t & 63;
     const int grp = __builtin_amdgcn_readfirstlane(t / TPR);  // y-group of this wave: scalar
     const int xt = t - grp * TPR;                             // lane position in the row
@@ -83,10 +85,8 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
     const long long per_copy = (long long)nby * g.nz, total = (dup_planes > 0 ? 2 : 1) * per_copy;
     const int nwg = (int)gridDim.x, wper = nwg >> 3;          // the launcher makes the grid a multiple of 8
     const int wi = (blockIdx.x & 7) * wper + (blockIdx.x >> 3);  // XCD-aware order: an XCD takes consecutive ranges
-    // zc == 0: ranges (above). zc > 0: z-chunks of zc planes, item = (copy, chunk, tile) with the tile running fastest, dealt
-    // round-robin: y-neighbouring tiles sit on neighbouring workgroups and march the same planes at the same time, so the halo
-    // rows they share are cache hits. Ranges keep that only when a range is a whole fraction of a tile's column; the launcher
-    // picks (wide_plan).
+    // (chunks: y-neighbouring tiles sit on neighbouring workgroups and march the same planes at the same time, so the halo rows
+    // they share are cache hits; ranges keep that only when a range is a whole fraction of a tile's column)
     const int nbz = zc > 0 ? (g.nz + zc - 1) / zc : 0;
     const long long items = (dup_planes > 0 ? 2 : 1) * (long long)nby * nbz;
     long long w0 = zc > 0 ? wi : total * wi / nwg;
