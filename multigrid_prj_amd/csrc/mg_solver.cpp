@@ -645,6 +645,7 @@ int Solver::gather_T(int which, int fullk)
 
 int Solver::scatter_T(int fullk, int which)
 {
+    pair_on_comm_level_ = -1;   // this call writes a level's arrays on the main stream: no exchange may skip its wait for that stream (every writer says so)
     Level &L = lv_[T_];
     const size_t pb = (size_t)L.g.plane * esize();
     char *b = reinterpret_cast<char *>(L.base[which]);
@@ -1170,6 +1171,7 @@ int Solver::restrict_to(int fine_level, int kind, int arr_src, int arr_dst)
 template <typename T>
 int Solver::prolong_t(int cl, int add, int as, int ad)
 {
+    pair_on_comm_level_ = -1;   // this call writes a level's arrays on the main stream: no exchange may skip its wait for that stream (every writer says so)
     if (lv_[cl].dist != lv_[cl - 1].dist) {
         set_last_error("transfer across the gather level is only available inside mg_cycle");
         return MG_ERR_BAD_ARG;
@@ -1196,6 +1198,7 @@ int Solver::prolong(int coarse_level, int add, int arr_src, int arr_dst)
 template <typename T>
 int Solver::correct_t(int level, int au, int ae)
 {
+    pair_on_comm_level_ = -1;   // this call writes a level's arrays on the main stream: no exchange may skip its wait for that stream (every writer says so)
     launch_correct<T>(stream_, lv_[level].g, ptr<T>(au, level), ptr<T>(ae, level));
     MG_HIP(hipGetLastError());
     return MG_OK;
@@ -1213,6 +1216,7 @@ int Solver::correct(int arr_u, int arr_e)
 template <typename T>
 int Solver::coarse_ex_t(int level, int ax, int ar, int smoother, int maxit, double tol, int fixed, bool x_zero)
 {
+    pair_on_comm_level_ = -1;   // this call writes a level's arrays on the main stream: no exchange may skip its wait for that stream (every writer says so)
     Level &L = lv_[level];
     launch_coarse_solve<T>(stream_, L.g, coef_of<T>(L), (T)d_.omega, smoother, ptr<T>(ax, level),
                            ptr<T>(MG_ARR_TMP, level), ptr<T>(ar, level), maxit, tol, fixed, d_coarse_, x_zero);
