@@ -353,6 +353,65 @@ def test_five_ranks_uneven_slabs_three_distributed_levels(mode, replicate, tmp_p
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("replicate,rb", [("1", False), ("0", False), ("1", True)])
+def test_eight_ranks_as_threads_uneven_slabs_equal_one_rank_and_the_oracle(replicate, rb, tmp_path, monkeypatch):
+    """EIGHT ranks of the real C++ path on the one GPU of the test box: the process guard admits six processes, so the ranks
+    are threads of this process, each with its own solver handle, and the host-callback transport is wired to in-process
+    mailboxes (tests/thread_ranks.py). fp32, n = 257, 5 levels, dist_min_n = 65: three distributed levels (257^3: slabs of 32
+    and 33 planes; 129^3: 16 and 17; 65^3: 8 and 9), the levels from 33^3 down replicated on every rank (all-gather) or kept on rank 0
+    (MG_REPLICATE_TAIL=0: gather + scatter); Jacobi and red-black. Eight ranks == one rank == the oracle, bit for bit."""
+    from multigrid_prj_amd import capi
+    from tests.thread_ranks import run_ranks
+    monkeypatch.setenv("MG_REPLICATE_TAIL", replicate)
+    case, desc, b = _case(tmp_path, 257, 5, 1, cycles=2, dtype=1, rb=rb)
+    desc["dist_min_n"] = 65
+    u, hists, sizes, fg, groups = run_ranks(desc, b, 8, case["cycles"])
+    assert fg == 3
+    assert sum(sizes) == 257 and sorted(set(sizes)) == [32, 33], sizes
+    assert all(g > 0 for g in groups)
+    with capi.Solver(capi.make_desc(**desc)) as s:
+        s.set_rhs(b)
+        for _ in range(case["cycles"]):
+            s.cycle()
+        h1, _ = s.solve(0.0, 2)
+        u1 = s.get_solution()
+    assert np.array_equal(u, u1)
+    u_ref, _ = _oracle(desc, b, case["cycles"])
+    assert np.array_equal(u, u_ref)
+    for h in hists:
+        np.testing.assert_allclose(h, h1, rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,levels,dtype", [(513, 6, 0), (1025, 7, 1)], ids=["513-fp64-benchmark-grid", "1025-fp32-config4"])
+def test_config4_as_worded_eight_ranks_full_size_equal_one_rank(n, levels, dtype):
+    """BASELINE config 4 AS WORDED -- 3-D Poisson 1025^3 fp32, 7 levels, V(2,2) Jacobi, 8 ranks -- and the benchmark grid
+    (513^3 fp64, 6 levels) on 8 ranks: eight thread-ranks on the one GPU (tests/thread_ranks.py), slabs of 128 / 129 (64 / 65)
+    planes, the wide-tile kernels on the interior pieces, boundary launches, halo reuse, the coarse levels replicated.
+    Two cycles + the residual history; the assembled solution must be the single-GPU solver's bit for bit (the single-GPU
+    solver against the oracle at these sizes: tests/test_gpu_parity.py)."""
+    from multigrid_prj_amd import capi
+    from tests.thread_ranks import run_ranks
+    desc = dict(dim=3, n=n, levels=levels, dtype=dtype, length=1.0, alpha=1.0, cycle=1, smoother=1, omega=6 / 7, nu_pre=2,
+                nu_post=2, restriction=1, coarse_mode=0, coarse_tol=0.1, coarse_maxit=2000, outer_pre_gs=0)
+    b = po.fill_rhs_3d(n, 1.0, 1.0, 1)
+    if dtype == 1:
+        b = b.astype(np.float32)
+    u, hists, sizes, fg, groups = run_ranks(desc, b, 8, 2)
+    assert sum(sizes) == n and max(sizes) - min(sizes) == 1, sizes
+    with capi.Solver(capi.make_desc(**desc)) as s:
+        s.set_rhs(b)
+        del b
+        for _ in range(2):
+            s.cycle()
+        h1, _ = s.solve(0.0, 2)
+        assert np.array_equal(u, s.get_solution())
+    for h in hists:
+        np.testing.assert_allclose(h, h1, rtol=1e-12 if dtype == 0 else 1e-6)
+    assert h1[2] < 0.4 * h1[1]
+
+
+@pytest.mark.gpu
 def test_rccl_transport_selftest():
     """The product transport (RCCL) cannot run two ranks on one GPU; at least exercise
     communicator creation, grouped ncclSend/ncclRecv and ncclAllReduce on this device."""
