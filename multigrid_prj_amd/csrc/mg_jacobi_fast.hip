@@ -816,13 +816,14 @@ bool rb_fused_ok(const Geom &g)
 }
 
 // coarse != nullptr: the sweep reads u + P coarse (prolong-add folded in, like launch_jacobi2_corr)
+// zero_u: u is identically zero and is not read (the first pre-smoothing sweep of a coarse level: its memset is skipped)
 template <typename T>
 void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs, T *out,
-                     const T *coarse, const Geom &gc, int dup)
+                     const T *coarse, const Geom &gc, int dup, bool zero_u)
 {
     constexpr int V = VecOf<T>::V;
-    if (coarse) dup = 0;   // the folding variant only runs on whole levels
-    if (pair_wide_ok<T>(g)) { launch_pair_wide<T>(s, g, gc, c, (T)1, u, coarse, rhs, out, false, true, dup); return; }
+    if (coarse) { dup = 0; zero_u = false; }   // the folding variant only runs on whole levels
+    if (pair_wide_ok<T>(g)) { launch_pair_wide<T>(s, g, gc, c, (T)1, u, coarse, rhs, out, zero_u, true, dup); return; }
     const int tpr = (g.nx - 1) / V;
     const int ncopy = (dup > 0 && !coarse) ? 2 : 1;
     static const int tyo_env = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
@@ -833,7 +834,9 @@ void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
 #define MG_RB2(TPR) \
     do { \
         if (coarse) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, coarse, gc, 0); \
+        else if (tyo == 3 && zero_u) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true, true, (TPR > 384) ? 2 : 3>), dim3(grid3), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}, dup); \
         else if (tyo == 3) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true, false, (TPR > 384) ? 2 : 3>), dim3(grid3), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby3, nbz, (const T *)nullptr, Geom{}, dup); \
+        else if (zero_u) hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}, dup); \
         else hipLaunchKernelGGL((k_jacobi2<T, TPR, false, true, false, true>), dim3(grid), dim3(TPR), 0, s, g, c, (T)1, u, rhs, out, nby, nbz, (const T *)nullptr, Geom{}, dup); \
     } while (0)
     switch (tpr) {
@@ -849,8 +852,8 @@ void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
 
 template bool rb_fused_ok<double>(const Geom &);
 template bool rb_fused_ok<float>(const Geom &);
-template void launch_rb_fused<double>(hipStream_t, const Geom &, const Coef<double> &, const double *, const double *, double *, const double *, const Geom &, int);
-template void launch_rb_fused<float>(hipStream_t, const Geom &, const Coef<float> &, const float *, const float *, float *, const float *, const Geom &, int);
+template void launch_rb_fused<double>(hipStream_t, const Geom &, const Coef<double> &, const double *, const double *, double *, const double *, const Geom &, int, bool);
+template void launch_rb_fused<float>(hipStream_t, const Geom &, const Coef<float> &, const float *, const float *, float *, const float *, const Geom &, int, bool);
 
 // prolong-add + two Jacobi sweeps in one pass: out = J(J(u + P coarse))
 template <typename T>

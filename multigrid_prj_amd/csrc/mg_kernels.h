@@ -66,7 +66,7 @@ template <typename T> void zebra_line_factors(T cl, T cd, int n, T *out);
 template <typename T> bool rb_fused_ok(const Geom &g);
 template <typename T>
 void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs, T *out,
-                     const T *coarse, const Geom &gc, int dup_planes = 0);
+                     const T *coarse, const Geom &gc, int dup_planes = 0, bool zero_u = false);
 // out-of-place colour half-sweep (the other colour is copied): red u->tmp, black tmp->u
 template <typename T>
 void launch_rb_fast(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, const T *u, const T *rhs, T *out);

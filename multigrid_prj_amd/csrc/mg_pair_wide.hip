@@ -564,7 +564,7 @@ int launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T>
 #define MG_PW_SHAPE(TPR, GG) \
     do { \
         if (norm) { if (damped) MG_PWN(TPR, GG, true); else MG_PWN(TPR, GG, false); } \
-        else if (rb) { if (coarse) MG_PW(TPR, GG, false, true, false, true); else MG_PW(TPR, GG, false, false, false, true); } \
+        else if (rb) { if (coarse) MG_PW(TPR, GG, false, true, false, true); else if (zero_u) MG_PW(TPR, GG, false, false, true, true); else MG_PW(TPR, GG, false, false, false, true); } \
         else if (coarse) { if (damped) MG_PW(TPR, GG, true, true, false, false); else MG_PW(TPR, GG, false, true, false, false); } \
         else if (zero_u) { if (damped) MG_PW(TPR, GG, true, false, true, false); else MG_PW(TPR, GG, false, false, true, false); } \
         else { if (damped) MG_PW(TPR, GG, true, false, false, false); else MG_PW(TPR, GG, false, false, false, false); } \

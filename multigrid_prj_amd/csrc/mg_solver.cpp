@@ -687,8 +687,11 @@ static Coef<T> coef_of(const Level &L)
 template <typename T>
 bool Solver::can_skip_zeroing(int level) const
 {
-    return d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre > 0 && level < d_.levels - 1 &&
-           fast_path_ok<T>(lv_[level].g);
+    if (d_.nu_pre <= 0 || level >= d_.levels - 1) return false;
+    if (d_.smoother == MG_SMOOTH_JACOBI) return fast_path_ok<T>(lv_[level].g);
+    // red-black: the one-pass sweep of an undistributed level (smooth_t takes exactly this branch for it)
+    static const bool rb_zero = [] { const char *e = getenv("MG_RB_ZERO_GUESS"); return !(e && e[0] == '0'); }();
+    return rb_zero && d_.smoother == MG_SMOOTH_RBGS && !lv_[level].dist && rb_fused_ok<T>(lv_[level].g);
 }
 
 // true when the V-cycle's prolong-add into `level` can be folded into the first post-smoothing pair
@@ -1009,7 +1012,8 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
             if (!L.dist && rb_fused_ok<T>(L.g)) {  // both colours in one pass over HBM; the sweep lands in TMP
                 const bool corr = (s == 0 && corr_level >= 0);
                 launch_rb_fused<T>(stream_, L.g, c, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
-                                   corr ? ptr<T>(ax, corr_level) : (const T *)nullptr, lv_[corr ? corr_level : level].g);
+                                   corr ? ptr<T>(ax, corr_level) : (const T *)nullptr, lv_[corr ? corr_level : level].g, 0,
+                                   x_zero && s == 0);
                 std::swap(L.base[ax], L.base[MG_ARR_TMP]);
                 launches++;
                 continue;
