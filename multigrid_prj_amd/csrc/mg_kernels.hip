@@ -1055,19 +1055,21 @@ __global__ __launch_bounds__(CoarseRowsThreads<SEG>::value) void k_coarse_jacobi
 // ---------------------------------------------------------------- LDS coarse solver, red-black GS
 // Solver::Solve (solvers.hpp:324-342) with the red-black smoother (BASELINE config 3's coarse solve: ~60 sweeps of 17^3 per
 // cycle) on the row-segment layout of k_coarse_jacobi_rows: a thread owns a run of SEG interior points of one row, own values
-// and right-hand sides in registers, ONE LDS copy of the iterate (the sweep is in place). A sweep is two colour phases -- every
-// thread evaluates all its points and keeps those of the phase's colour ((x + y + z) & 1): the others' inputs are mid-update
-// and their values are dropped -- and the residual pass, three barriers in all, where the generic loop (k_coarse_solve_lds)
-// re-derives every point's indices in each of its passes (7.6 us per sweep; this one ~3). Same point_update / residual
-// expressions => the iterate is bit-identical after the same number of sweeps (tests/test_gpu_parity.py::test_coarse_solver).
+// and right-hand sides in registers, two LDS copies of the iterate. A sweep is two colour phases -- every thread evaluates all
+// its points and keeps those of the phase's colour ((x + y + z) & 1): the others' values are dropped -- and the residual of
+// the previous iterate rides on the red phase (same neighbours): two LDS passes and two barriers per sweep (see the loop),
+// where the generic loop (k_coarse_solve_lds) re-derives every point's indices in each of its three passes (7.6 us per
+// sweep; this one ~2). Same point_update / residual expressions => the iterate is bit-identical after the same number of
+// sweeps (tests/test_gpu_parity.py::test_coarse_solver). zero_x: the guess is zero and x has not been cleared.
 template <typename T, int DIM, int SEG>
 __global__ __launch_bounds__(CoarseRowsThreads<SEG>::value) void k_coarse_rb_rows(Geom g, Coef<T> c, T *x, const T *rhs, int maxit,
-                                                                                  double tol, int fixed, CoarseOut *out)
+                                                                                  double tol, int fixed, CoarseOut *out, int zero_x)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ double part[2][SWG / 64];
     const int nx = g.nx, ny = g.ny, npl = nx * ny, total = npl * g.nz;
     T *cur = reinterpret_cast<T *>(smem_raw);
+    T *nxt = cur + total;
     const int W = nx - 2, nseg = (W + SEG - 1) / SEG;
     const int irows = (ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
     const int nthr = (int)blockDim.x;
@@ -1094,7 +1096,8 @@ __global__ __launch_bounds__(CoarseRowsThreads<SEG>::value) void k_coarse_rb_row
     double sqb = 0.;
     for (int q = tid; q < total; q += nthr) {
         const long long gi = dense_to_global(q);
-        cur[q] = x[gi];
+        const T xq = zero_x ? (T)0 : x[gi];
+        cur[q] = xq; nxt[q] = xq;
         const double t = (double)rhs[gi];
         sqb += t * t;
     }
@@ -1104,7 +1107,7 @@ __global__ __launch_bounds__(CoarseRowsThreads<SEG>::value) void k_coarse_rb_row
         xv[k] = 0; bv[k] = 0;
         if (active) {
             const long long gi = lidx(g, z, y, x0 + k);
-            xv[k] = x[gi]; bv[k] = rhs[gi];
+            xv[k] = zero_x ? (T)0 : x[gi]; bv[k] = rhs[gi];
         }
     }
     int parity = 0;
@@ -1128,88 +1131,104 @@ __global__ __launch_bounds__(CoarseRowsThreads<SEG>::value) void k_coarse_rb_row
         }
         return sqrt(nr / nb) > tol;  // NaN (zero rhs) compares false, like the reference
     };
-    // sum r^2 of the current iterate; with_bnd: the Dirichlet nodes still hold the initial guess (before the first sweep:
-    // r = b - 1 * x; after it x == b there and r == b - 1 * b == 0 exactly)
-    auto residual = [&](bool with_bnd) -> double {
+    // One trip = the residual norm of the current iterate u_k AND sweep k+1, two LDS passes and two barriers:
+    //   pass A (reads cur = u_k): r = b - A u_k on every own point (sum of squares -> the norm test) and, from the same
+    //          neighbours, the red points of sweep k+1, stored to nxt; block_sum = barrier. If the test says stop, u_k is
+    //          still whole in cur and the tentative reds are dropped (the reference tests before it sweeps, solvers.hpp:329);
+    //   pass B (reads nxt): the black points from the new reds, stored to nxt; barrier; swap.
+    // A black point's neighbours are all red and vice versa, so nxt is complete after pass B; values a pass computes on
+    // points of the other colour (from mixed or stale neighbours) are dropped. The Dirichlet nodes turn into b during the
+    // first sweep (both buffers get them in the first two trips); their residual is b - 1 * x before it and exactly 0 after.
+    int iters = 0, flag = 0, counter = maxit;
+    double nr;
+    for (;;) {
         double sq = 0.;
-        if (with_bnd) {
+        if (iters < 2) {
             for (int q = tid; q < total; q += nthr) {
                 if (bnd_colour(q) >= 0) {
-                    const T res = rhs[dense_to_global(q)] - (T)1 * cur[q];
+                    const T bq = rhs[dense_to_global(q)];
+                    const T res = bq - (T)1 * cur[q];
                     sq += (double)res * (double)res;
+                    nxt[q] = bq;
                 }
             }
         }
+        T nv[SEG];
+#pragma unroll
+        for (int k = 0; k < SEG; k++) nv[k] = xv[k];
         if (active) {
             const T el = cur[i0 - 1], er = cur[i0 + SEG];
+            T ym[SEG], yp[SEG], zm[SEG], zp[SEG], num[SEG], quo[SEG];
+#pragma unroll
+            for (int k = 0; k < SEG; k++) {
+                ym[k] = cur[i0 + k - nx]; yp[k] = cur[i0 + k + nx];
+                zm[k] = 0; zp[k] = 0;
+                if (DIM == 3) { zm[k] = cur[i0 + k - npl]; zp[k] = cur[i0 + k + npl]; }
+            }
 #pragma unroll
             for (int k = 0; k < SEG; k++) {
                 const T left = (k == 0) ? el : xv[k > 0 ? k - 1 : 0];
                 const T right = (k == SEG - 1) ? er : xv[k < SEG - 1 ? k + 1 : 0];
                 T fs = 0;  // residual row, diagonal included (solvers.hpp:269-271)
-                if (DIM == 3) fs += c.cz * cur[i0 + k - npl];
-                fs += c.cy * cur[i0 + k - nx];
+                if (DIM == 3) fs += c.cz * zm[k];
+                fs += c.cy * ym[k];
                 fs += c.cx * left;
                 fs += c.cd * xv[k];
                 fs += c.cx * right;
-                fs += c.cy * cur[i0 + k + nx];
-                if (DIM == 3) fs += c.cz * cur[i0 + k + npl];
+                fs += c.cy * yp[k];
+                if (DIM == 3) fs += c.cz * zp[k];
                 const T res = bv[k] - fs;
                 const double r2 = (double)res * (double)res;
                 sq += (k == 0 && dup0) ? 0. : r2;
+                T os = 0;  // Gauss-Seidel row, off-diagonals only (solvers.hpp:36-46)
+                if (DIM == 3) os += c.cz * zm[k];
+                os += c.cy * ym[k];
+                os += c.cx * left;
+                os += c.cx * right;
+                os += c.cy * yp[k];
+                if (DIM == 3) os += c.cz * zp[k];
+                num[k] = bv[k] - os;
+            }
+            div_cd_n<T, SEG>(num, quo, c);
+#pragma unroll
+            for (int k = 0; k < SEG; k++) {
+                if (((p0 + k) & 1) == 0) { nv[k] = quo[k]; nxt[i0 + k] = quo[k]; }
             }
         }
-        return block_sum(sq);
-    };
-    auto half_sweep = [&](int colour, bool first) {
-        if (first) {   // the Dirichlet nodes of this colour: x <- b (point_update on a boundary node)
-            for (int q = tid; q < total; q += nthr)
-                if (bnd_colour(q) == colour) cur[q] = rhs[dense_to_global(q)];
-        }
-        if (active) {
-            const T el = cur[i0 - 1], er = cur[i0 + SEG];
+        nr = block_sum(sq);
+        bool go;
+        if (fixed) go = iters < maxit;
+        else if (above_tol(nr)) { go = counter > 0; if (!go) flag = 1; }
+        else go = false;
+        if (!go) break;   // uniform: every thread sees the same nr
+#pragma unroll
+        for (int k = 0; k < SEG; k++) xv[k] = nv[k];
+        if (active) {   // black points from the new reds
+            const T el = nxt[i0 - 1], er = nxt[i0 + SEG];
             T num[SEG], quo[SEG];
 #pragma unroll
             for (int k = 0; k < SEG; k++) {
                 const T left = (k == 0) ? el : xv[k > 0 ? k - 1 : 0];
                 const T right = (k == SEG - 1) ? er : xv[k < SEG - 1 ? k + 1 : 0];
                 T os = 0;
-                if (DIM == 3) os += c.cz * cur[i0 + k - npl];
-                os += c.cy * cur[i0 + k - nx];
+                if (DIM == 3) os += c.cz * nxt[i0 + k - npl];
+                os += c.cy * nxt[i0 + k - nx];
                 os += c.cx * left;
                 os += c.cx * right;
-                os += c.cy * cur[i0 + k + nx];
-                if (DIM == 3) os += c.cz * cur[i0 + k + npl];
+                os += c.cy * nxt[i0 + k + nx];
+                if (DIM == 3) os += c.cz * nxt[i0 + k + npl];
                 num[k] = bv[k] - os;
             }
             div_cd_n<T, SEG>(num, quo, c);
 #pragma unroll
             for (int k = 0; k < SEG; k++) {
-                if (((p0 + k) & 1) == colour) { xv[k] = quo[k]; cur[i0 + k] = quo[k]; }
+                if (((p0 + k) & 1) == 1) { xv[k] = quo[k]; nxt[i0 + k] = quo[k]; }
             }
         }
         __syncthreads();
-    };
-    int iters = 0, flag = 0;
-    double nr;
-    auto sweep = [&]() { half_sweep(0, iters == 0); half_sweep(1, iters == 0); };
-    if (fixed) {
-        for (int s = 0; s < maxit; s++) { sweep(); iters++; }
-        nr = residual(iters == 0);
-    } else {
-        int counter = maxit;
-        nr = residual(true);
-        while (above_tol(nr)) {
-            if (counter > 0) {
-                sweep();
-                counter -= 1;
-                iters++;
-                nr = residual(false);
-            } else {
-                flag = 1;
-                break;
-            }
-        }
+        T *t_ = cur; cur = nxt; nxt = t_;
+        counter -= 1;
+        iters++;
     }
     __syncthreads();
     for (int q = tid; q < total; q += nthr) x[dense_to_global(q)] = cur[q];
@@ -1816,9 +1835,9 @@ static bool try_launch_coarse_jacobi(hipStream_t s, const Geom &g, const Coef<T>
 
 template <typename T, int DIM, int SEG>
 static bool try_launch_coarse_rb_rows(hipStream_t s, const Geom &g, const Coef<T> &c, T *x, const T *rhs, int maxit, double tol,
-                                      int fixed, CoarseOut *d_out)
+                                      int fixed, CoarseOut *d_out, int zero_x)
 {
-    const size_t total = (size_t)g.nx * g.ny * g.nz, bytes = total * sizeof(T);
+    const size_t total = (size_t)g.nx * g.ny * g.nz, bytes = 2 * total * sizeof(T);   // two copies of the iterate
     const int W = g.nx - 2, nseg = (W + SEG - 1) / SEG;
     if (W < SEG || nseg * SEG - W > 1) return false;  // full runs, at most one shared point per row
     const int threads = nseg * (g.ny - 2) * (DIM == 3 ? g.nz - 2 : 1);
@@ -1830,14 +1849,14 @@ static bool try_launch_coarse_rb_rows(hipStream_t s, const Geom &g, const Coef<T
                                 150 * 1024) != hipSuccess) return false;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(((threads + 63) / 64) * 64), bytes, s, g, c, x, rhs, maxit, tol, fixed, d_out);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(((threads + 63) / 64) * 64), bytes, s, g, c, x, rhs, maxit, tol, fixed, d_out, zero_x);
     return true;
 }
 
 // red-black coarse solve on the row-segment layout (MG_COARSE_RB_ROWS=0: the generic LDS kernel)
 template <typename T, int DIM>
 static bool try_launch_coarse_rb(hipStream_t s, const Geom &g, const Coef<T> &c, T *x, const T *rhs, int maxit, double tol,
-                                 int fixed, CoarseOut *d_out)
+                                 int fixed, CoarseOut *d_out, int zero_x)
 {
     static const bool enabled = [] { const char *e = getenv("MG_COARSE_RB_ROWS"); return !(e && e[0] == '0'); }();
     if (!enabled || g.ny < 3 || (DIM == 3 && g.nz < 3)) return false;
@@ -1845,8 +1864,8 @@ static bool try_launch_coarse_rb(hipStream_t s, const Geom &g, const Coef<T> &c,
     for (int seg : {5, 4}) {   // (runs of 7 / 8 points: the colour selects went through scratch memory; not instantiated)
         const int nseg = (W + seg - 1) / seg, threads = nseg * irows;
         if (W < seg || nseg * seg - W > 1 || threads < 128 || threads > SWG) continue;
-        if (seg == 5) return try_launch_coarse_rb_rows<T, DIM, 5>(s, g, c, x, rhs, maxit, tol, fixed, d_out);
-        return try_launch_coarse_rb_rows<T, DIM, 4>(s, g, c, x, rhs, maxit, tol, fixed, d_out);
+        if (seg == 5) return try_launch_coarse_rb_rows<T, DIM, 5>(s, g, c, x, rhs, maxit, tol, fixed, d_out, zero_x);
+        return try_launch_coarse_rb_rows<T, DIM, 4>(s, g, c, x, rhs, maxit, tol, fixed, d_out, zero_x);
     }
     return false;
 }
@@ -1874,11 +1893,15 @@ void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega
                          T *x, T *tmp, const T *rhs, int maxit, double tol, int fixed,
                          CoarseOut *d_out, bool x_is_zero)
 {
-    // x_is_zero: the solve starts from the zero guess and the caller has NOT cleared x: the row-segment Jacobi kernel takes the
+    // x_is_zero: the solve starts from the zero guess and the caller has NOT cleared x: the row-segment Jacobi and red-black kernels take the
     // guess as a flag (a memset launch less per cycle); every other kernel gets its x cleared here
     if (x_is_zero && smoother == 1 && g.gz0 == 0 && g.gnz == g.nz) {
         if (g.dim == 3 ? try_launch_coarse_jacobi<T, 3>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, 1)
                        : try_launch_coarse_jacobi<T, 2>(s, g, c, omega, x, rhs, maxit, tol, fixed, d_out, 1)) return;
+    }
+    if (x_is_zero && smoother == 2 && g.gz0 == 0 && g.gnz == g.nz) {  // so does the row-segment red-black kernel
+        if (g.dim == 3 ? try_launch_coarse_rb<T, 3>(s, g, c, x, rhs, maxit, tol, fixed, d_out, 1)
+                       : try_launch_coarse_rb<T, 2>(s, g, c, x, rhs, maxit, tol, fixed, d_out, 1)) return;
     }
     if (x_is_zero) (void)hipMemsetAsync(x, 0, (size_t)g.nz * (size_t)g.plane * sizeof(T), s);
     // LDS-resident when the three arrays fit one CU's LDS, global-memory loop otherwise
@@ -1888,8 +1911,8 @@ void launch_coarse_solve(hipStream_t s, const Geom &g, const Coef<T> &c, T omega
     }
     if (smoother == 0 && try_launch_coarse_gs_rows2d<T>(s, g, c, x, rhs, maxit, tol, fixed, d_out)) return;
     if (smoother == 2 && g.gz0 == 0 && g.gnz == g.nz) {  // red-black: the row-segment kernel
-        if (g.dim == 3 ? try_launch_coarse_rb<T, 3>(s, g, c, x, rhs, maxit, tol, fixed, d_out)
-                       : try_launch_coarse_rb<T, 2>(s, g, c, x, rhs, maxit, tol, fixed, d_out)) return;
+        if (g.dim == 3 ? try_launch_coarse_rb<T, 3>(s, g, c, x, rhs, maxit, tol, fixed, d_out, 0)
+                       : try_launch_coarse_rb<T, 2>(s, g, c, x, rhs, maxit, tol, fixed, d_out, 0)) return;
     }
     if (g.dim == 3) {
         if (try_launch_coarse_lds<T, 3, 5>(s, g, c, omega, smoother, x, rhs, maxit, tol, fixed, d_out)) return;
