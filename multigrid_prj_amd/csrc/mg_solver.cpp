@@ -281,6 +281,15 @@ int Solver::init()
             }
         }
         if (!L.dist) L.nz_min = L.g.nz;
+        {
+            // Interior / boundary split with the exchange on the communication stream: two cross-stream waits (6-20 us each on
+            // this chip) and a boundary launch per operation. It pays while the interior launch is longer than the exchange;
+            // on a slab of a few MB (257^3 on 8 ranks: 17 MB per array, interior pair 20 us, halo 1 MB per neighbour) it does
+            // not, and exchange-then-one-launch takes the same time with free communication 13-20 us less per operation.
+            const char *e = getenv("MG_OVERLAP_MIN_MB");   // read per handle (tests switch it between handles of one process)
+            const double min_mb = e ? atof(e) : 32.0;
+            L.overlap = overlap_ && L.dist && (double)L.nz_min * (double)L.g.plane * (double)esize() >= min_mb * 1048576.0;
+        }
         L.gh = L.dist ? 2 : 1;
         L.alloc_elems = (size_t)(L.g.nz + 2 * L.gh) * (size_t)L.g.plane;
         if (!L.present) continue;
@@ -543,7 +552,7 @@ int Solver::overlapped(int level, int arr_x, F &&launch)
 {
     Level &L = lv_[level];
     if (!L.dist) { launch(L.g, (long long)0); return MG_OK; }
-    if (!overlap_ || L.g.nz < 4) {
+    if (!L.overlap || L.g.nz < 4) {
         MG_TRY(exchange(arr_x, level));
         launch(L.g, (long long)0);
         return MG_OK;
@@ -713,6 +722,23 @@ bool Solver::can_fold_prolong_slab(int level) const
            jacobi2_corr_slab_ok<T>(lv_[level].g, lv_[level + 1].g);
 }
 
+// the last distributed level over the first replicated one (MG_REPLICATE_TAIL): every rank holds the whole coarse correction, the
+// kernels address coarse planes by global index, so the slab pair folds P e in straight from the replicated array -- no copy
+// of the rank's planes into the staging slab, no prolongation launch (13-15 us per cycle at 513^3 on 8 ranks)
+template <typename T>
+bool Solver::can_fold_prolong_replicated(int level) const
+{
+    static const bool enabled = [] {
+        const char *e = getenv("MG_FUSED_PROLONG"), *r = getenv("MG_FUSED_PROLONG_REPLICATED");
+        return !(e && e[0] == '0') && !(r && r[0] == '0');
+    }();
+    if (!enabled || !replicate_ || level + 1 >= d_.levels || !lv_[level].dist || lv_[level + 1].dist || !lv_[level + 1].present) return false;
+    if (d_.smoother != MG_SMOOTH_JACOBI || d_.nu_post < 2 || !depth2_enabled()) return false;
+    const Geom &gf = lv_[level].g, &gc = lv_[level + 1].g;
+    return jacobi2_slab_ok<T>(slab_gate_geom(lv_[level])) && gc.dim == 3 && gf.nx == 2 * gc.nx - 1 && gf.ny == 2 * gc.ny - 1 &&
+           gf.gnz == 2 * gc.gnz - 1 && gc.gz0 == 0 && gc.gnz == gc.nz && lv_[level].nz_min >= 4;
+}
+
 template <typename T>
 bool Solver::can_fold_prolong(int level) const
 {
@@ -820,7 +846,7 @@ int Solver::pair_on_slab2_t(int level, bool rb, int corr_level, bool u_halo_ok)
     // corr_level >= 0 (Jacobi): the pair also applies the coarse correction, out = J(J(u + P e)): e's two ghost planes either
     // side come first (the separate prolongation fetched one), then every piece is the folding kernel
     const T *pe = corr_level >= 0 ? ptr<T>(MG_ARR_U, corr_level) : (const T *)nullptr;
-    if (corr_level >= 0) MG_TRY(exchange(MG_ARR_U, corr_level, 2));
+    if (corr_level >= 0 && lv_[corr_level].dist) MG_TRY(exchange(MG_ARR_U, corr_level, 2));   // (a replicated level is whole on every rank)
     auto fused = [&](const Geom &gs, long long off, int dup = 0, hipStream_t st = nullptr) {
         if (!st) st = stream_;
         if (pe) launch_jacobi2_corr<T>(st, gs, lv_[corr_level].g, c, om, px + off, pe, pr + off, pt + off, dup);
@@ -832,7 +858,7 @@ int Solver::pair_on_slab2_t(int level, bool rb, int corr_level, bool u_halo_ok)
     static const bool reuse_halo = [] { const char *e = getenv("MG_REUSE_HALO"); return !(e && e[0] == '0'); }();
     if (u_halo_ok && reuse_halo) {
         fused(g, 0);
-    } else if (!overlap_ || g.nz < 8) {
+    } else if (!L.overlap || g.nz < 8) {
         MG_TRY(exchange(MG_ARR_U, level, 2));
         fused(g, 0);
     } else {
@@ -875,7 +901,7 @@ int Solver::resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs)
     const int pair_level = pair_on_comm_level_;
     pair_on_comm_level_ = -1;
     const bool semi = gf.gnz == gc.gnz;          // planes map one to one
-    if (!overlap_ || gc.nz < 4 || semi) {
+    if (!L.overlap || gc.nz < 4 || semi) {
         MG_TRY(exchange(MG_ARR_U, level, 2));
         launch_resid_restrict_fw<T>(stream_, gf, gc, c, pu, pr, coarse_rhs);
     } else {
@@ -952,7 +978,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
                 s++; launches += 1;   // counted as ONE segment: exchange + interior + boundary launches
                 continue;
             }
-            if (L.dist && overlap_ && e_scratch && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps &&
+            if (L.dist && L.overlap && e_scratch && ax == MG_ARR_U && ar == MG_ARR_RHS && s + 1 < sweeps &&
                 !(x_zero && s == 0) && jacobi2_slab_ok<T>(slab_gate_geom(L))) {  // E is free in a V-cycle: scratch for the boundary planes' first sweep
                 MG_TRY(pair_on_slab_t<T>(level, false));
                 s++; launches += 1;
@@ -1003,7 +1029,7 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
                 launches += 1;
                 continue;
             }
-            if (L.dist && overlap_ && e_scratch && ax == MG_ARR_U && ar == MG_ARR_RHS &&
+            if (L.dist && L.overlap && e_scratch && ax == MG_ARR_U && ar == MG_ARR_RHS &&
                 jacobi2_slab_ok<T>(slab_gate_geom(L)) && rb_slab_enabled()) {  // one-pass red-black sweep on the slab's inner planes
                 MG_TRY(pair_on_slab_t<T>(level, true));
                 launches += 1;
@@ -1372,11 +1398,15 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
             if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
             MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
         }
-        MG_TRY(scatter_S(MG_ARR_U));
-        if (prof) MG_TRY(prof_begin(l));
-        launch_prolong<T>(stream_, stage_g_, lv_[l].g, stageptr<T>(1), ptr<T>(MG_ARR_U, l), true);
-        MG_HIP(hipGetLastError());
-        if (prof) MG_TRY(prof_end(l, MG_PROF_PROLONG, 1, 1));
+        if (fuse_rr_slab && can_fold_prolong_replicated<T>(l)) {
+            fold = fold_slab = true;   // the post-smoothing pair reads the correction from the replicated level's own array
+        } else {
+            MG_TRY(scatter_S(MG_ARR_U));
+            if (prof) MG_TRY(prof_begin(l));
+            launch_prolong<T>(stream_, stage_g_, lv_[l].g, stageptr<T>(1), ptr<T>(MG_ARR_U, l), true);
+            MG_HIP(hipGetLastError());
+            if (prof) MG_TRY(prof_end(l, MG_PROF_PROLONG, 1, 1));
+        }
     } else if (mine) {
         if (fuse_rr_slab) {
             lv_[l + 1].rhs_halo_ok = false;

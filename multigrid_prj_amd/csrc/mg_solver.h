@@ -44,6 +44,8 @@ struct Level {
     int nz_min = 0;              // thinnest slab of the level over all ranks (== g.nz when the level is not distributed)
     int gh = 1;                  // ghost planes either side of the owned ones: 2 on distributed levels (one exchange then
                                  // feeds a fused sweep pair / residual + restriction), 1 elsewhere (unused, zero)
+    bool overlap = false;        // distributed level whose slabs are big enough for the interior launch to hide the halo exchange
+                                 // (MG_OVERLAP_MIN_MB, decided on the thinnest slab: the same answer on every rank)
     bool rhs_halo_ok = false;    // distributed level: the RHS array's first ghost planes hold the neighbours' planes
     void *zebra = nullptr;       // MG_SMOOTH_ZEBRA_Y / _X: cp(j), den(j) of the line solve (2 * ny or 2 * nx values, device)
 };
@@ -100,6 +102,7 @@ private:
                                        int corr_level = -1, bool e_scratch = false, bool u_halo_ok = false);
     template <typename T> bool can_fold_prolong(int level) const;
     template <typename T> bool can_fold_prolong_slab(int level) const;   // both levels distributed: the slab pair folds P e in
+    template <typename T> bool can_fold_prolong_replicated(int level) const;   // slab level over a level every rank holds whole
     template <typename T> int pair_on_slab_t(int level, bool rb);
     template <typename T> int pair_on_slab2_t(int level, bool rb, int corr_level = -1, bool u_halo_ok = false);   // depth-2 ghosts: one exchange, the fused kernel on the whole slab
     template <typename T> int resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs);

@@ -29,7 +29,11 @@ def _free_port():
 
 
 def _rank_env(mode, r, extra_env):
-    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    # MG_OVERLAP_MIN_MB=0: interior / boundary overlap on every distributed level, however small (the library's default keeps
+    # it for slabs of >= 32 MB per array; the small grids of these tests would never take it) -- a test asks for the default
+    # policy with extra_env={"MG_OVERLAP_MIN_MB": "32"}
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", MG_OVERLAP_MIN_MB="0")
+    env.update(extra_env or {})
     if mode == "rccl":
         # RCCL refuses two ranks of one host on one device; ranks that claim hosts of their own are accepted and talk over
         # the socket transport (loopback): the product's RcclComm with real peers on a one-GPU box
@@ -130,6 +134,25 @@ def test_hip_distributed_solver_two_processes_one_gpu(world, n, levels, restrict
     assert np.array_equal(u, u_ref)
     for h in hists:
         np.testing.assert_allclose(h, h1, rtol=1e-12 if dtype == 0 else 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,levels,dtype,rb", [(2, 257, 4, 0, False), (3, 257, 5, 1, False), (2, 129, 4, 0, True)])
+def test_hip_distributed_default_overlap_policy_small_slabs_take_one_launch(world, n, levels, dtype, rb, tmp_path):
+    """The library's own policy (MG_OVERLAP_MIN_MB = 32): slabs of a few MB exchange first and run ONE launch per operation
+    instead of interior + boundary pieces on two streams. Same bits as one GPU and the oracle."""
+    from multigrid_prj_amd import capi
+    case, desc, b = _case(tmp_path, n, levels, 1, dtype=dtype, rb=rb)
+    u, hists, fg = _run_ranks("hip", world, case, tmp_path, extra_env={"MG_OVERLAP_MIN_MB": "32"})
+    with capi.Solver(capi.make_desc(**desc)) as s:
+        s.set_rhs(b)
+        for _ in range(case["cycles"]):
+            s.cycle()
+        s.solve(0.0, 2)
+        u1 = s.get_solution()
+    assert np.array_equal(u, u1)
+    u_ref, _ = _oracle(desc, b, case["cycles"])
+    assert np.array_equal(u, u_ref)
 
 
 @pytest.mark.gpu
@@ -276,6 +299,29 @@ def test_hip_distributed_prolongation_fold_on_slabs(world, n, levels, dtype, tmp
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,dtype,policy", [(2, 0, "0"), (3, 1, "32")])
+def test_hip_prolongation_fold_from_the_replicated_level(world, dtype, policy, tmp_path):
+    """The last distributed level over the first REPLICATED one (257^3 on slabs, 129^3 whole on every rank): the post-smoothing
+    pair of the slab reads the coarse correction straight from the replicated array (coarse planes by global index) -- no
+    staging copy, no prolongation launch -- with and without the interior / boundary overlap; MG_FUSED_PROLONG_REPLICATED=0
+    takes the copy + prolongation. Same bits either way, as one GPU and as the oracle."""
+    from multigrid_prj_amd import capi
+    case, desc, b = _case(tmp_path, 257, 4, 1, cycles=3, dtype=dtype)
+    desc["dist_min_n"] = 257          # only 257^3 is distributed; 129^3, 65^3, 33^3 are replicated
+    case["desc"] = desc
+    res = {}
+    for fold in ("1", "0"):
+        u, hists, fg = _run_ranks("hip", world, case, tmp_path, extra_env={"MG_FUSED_PROLONG_REPLICATED": fold, "MG_OVERLAP_MIN_MB": policy})
+        assert fg == 1
+        res[fold] = (u, [int(p["fold_launches"]) for p in _run_ranks.last_parts], [int(p["prolong_launches"]) for p in _run_ranks.last_parts])
+    assert all(f == 2 for f in res["1"][1]) and all(p == 0 for p in res["1"][2]), res["1"][1:]   # two profiled cycles, folded
+    assert all(f == 0 for f in res["0"][1]) and all(p == 2 for p in res["0"][2]), res["0"][1:]   # ... copy + prolongation
+    assert np.array_equal(res["1"][0], res["0"][0])
+    u_ref, _ = _oracle(desc, b, case["cycles"])
+    assert np.array_equal(res["1"][0], u_ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rb", [False, True])
 def test_hip_distributed_public_smooth_leaves_e_alone(rb, tmp_path):
     """mg_smooth(level, ..., U, RHS) on a distributed level: the caller's E array survives (the V-cycle's
@@ -363,6 +409,7 @@ def test_eight_ranks_as_threads_uneven_slabs_equal_one_rank_and_the_oracle(repli
     from multigrid_prj_amd import capi
     from tests.thread_ranks import run_ranks
     monkeypatch.setenv("MG_REPLICATE_TAIL", replicate)
+    monkeypatch.setenv("MG_OVERLAP_MIN_MB", "0")   # interior / boundary overlap on these 32-plane slabs too
     case, desc, b = _case(tmp_path, 257, 5, 1, cycles=2, dtype=1, rb=rb)
     desc["dist_min_n"] = 65
     u, hists, sizes, fg, groups = run_ranks(desc, b, 8, case["cycles"])
