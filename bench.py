@@ -67,6 +67,11 @@ def parse(argv=None):
     ap.add_argument("--dry-rank", type=int, default=-1,
                     help="MEASUREMENT TOOL, one process, one GPU: run rank R of --gpus N with no peers (every exchange is a "
                          "no-op, results meaningless) to time that rank's compute schedule; the line is marked dry_run")
+    ap.add_argument("--dry-raw-coarse", action="store_true",
+                    help="with --dry-rank: leave the coarse solve uncapped. By default the dry run caps its coarse-grid sweeps at the "
+                         "count the real problem takes (measured first on this GPU with the single-GPU solver, same cycles): without "
+                         "exchanges the slab's data are inconsistent at its faces and the 17^3 solve needs 1.4x the sweeps, which "
+                         "k ranks == 1 rank rules out for a real run")
     ap.add_argument("--rccl-same-gpu", action="store_true",
                     help="REHEARSAL on a one-GPU box: every rank uses GPU 0 and tells RCCL it sits on a host of its own (NCCL_HOSTID), "
                          "so that RCCL accepts two ranks on one device and carries the messages over its socket transport on the "
@@ -260,9 +265,19 @@ def main():
             host_comm = torch_host_comm()
 
     desc = workload_desc(capi, a)
+    npdt = np.float64 if a.dtype == "f64" else np.float32
+    dry_coarse = None
+    if dry and not a.dry_raw_coarse and not a.semi:
+        # k ranks == 1 rank bit for bit, so a real N-rank run makes exactly the single-GPU run's coarse sweeps: count them
+        # (same cycles as the timed region) and cap the dry run's coarse solve there -- same kernel, same tests per sweep
+        with capi.Solver(workload_desc(capi, a), device=device) as s1:
+            s1.set_rhs(hash_rhs(a.n, npdt))
+            s1.zero_array(capi.ARR_U, 0)
+            counts = [s1.cycle().coarse_iters for _ in range(a.warmup + a.steps)]
+        dry_coarse = {"single_gpu_sweeps_per_cycle": float(np.mean(counts[a.warmup:])), "capped_at": max(1, int(round(np.mean(counts[a.warmup:]))))}
+        desc.coarse_maxit = dry_coarse["capped_at"]
     s = capi.Solver(desc, device=device, rank=rank, nranks=world, comm_id=comm_id, host_comm=host_comm, dry=dry)
     z0, nz, first_gathered = capi.plan_slab(desc, world, rank, 0)
-    npdt = np.float64 if a.dtype == "f64" else np.float32
     s.set_rhs(hash_rhs(a.n, npdt, z0, nz))
     s.zero_array(capi.ARR_U, 0)
     _, _, transport_ranks, transport_name = s.comm_info()
@@ -393,7 +408,8 @@ def main():
                                   f"coarse {((a.n - 1) >> (a.levels - 1)) + 1}^3 iterated to rel. residual 0.1, {a.dtype}"),
                    "parallelism": (f"z-slab x{world}" + ("" if a.transport == "rccl" else " (gloo rehearsal)") + (" (RCCL rehearsal: all ranks on GPU 0, socket transport)" if a.rccl_same_gpu else "")) if world > 1 else "single GPU",
                    "first_gathered_level": first_gathered},
-        **({"dry_run": f"rank {rank} of {world} WITHOUT communication: one rank's compute schedule, not a result"} if dry else {}),
+        **({"dry_run": f"rank {rank} of {world} WITHOUT communication: one rank's compute schedule, not a result",
+            "dry_run_coarse_sweeps": dry_coarse} if dry else {}),
         "transport": transport_name, "rccl_ranks": transport_ranks if transport_name == "rccl" else None,
         "ms_per_step_ranks": per_rank_ms,
         # what rank 0 posts per cycle: message groups (halo exchanges, gather, scatter: one ncclGroup each) and bytes sent

@@ -53,6 +53,7 @@ def test_bench_dry_rank_runs_one_ranks_schedule_on_one_gpu():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert "dry_run" in out and "WITHOUT communication" in out["dry_run"]
+    assert out["dry_run_coarse_sweeps"]["capped_at"] >= 1     # the coarse solve is capped at the real problem's sweep count
     assert out["transport"] == "dry-run" and out["rccl_ranks"] is None and out["n_gpus"] == 4
     assert out["comm_per_cycle"]["message_groups"] > 0 and out["ms_per_step"] > 0
     # every finest-level row is priced per SEGMENT (exchange + interior + boundary launches count as one): one per cycle timed
