@@ -15,7 +15,8 @@ def main():
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?"))))
+            wgs = int(r.get("Grid_Size_X", 0) or 0) // max(int(r.get("Workgroup_Size_X", 1) or 1), 1)
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?")), wgs))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if marker in r[2]]
     if len(marks) < 3:
@@ -28,11 +29,11 @@ def main():
     busy = 0
     per = defaultdict(lambda: [0, 0.0])
     print(f"cycle of {len(cyc)} launches, {(cyc[-1][1] - t0) / 1e3:.1f} us from the end of one coarse solve to the end of the next")
-    print(f"{'start us':>9} {'gap us':>7} {'dur us':>8} stream  kernel")
-    for s, e, name, q in cyc:
+    print(f"{'start us':>9} {'gap us':>7} {'dur us':>8} stream  {'wgs':>6}  kernel")
+    for s, e, name, q, wgs in cyc:
         gap = (s - end_prev) / 1e3
         short = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("mg::", "").split("(")[0][:80]
-        print(f"{(s - t0) / 1e3:9.1f} {gap:7.1f} {(e - s) / 1e3:8.1f} {q:>6}  {short}")
+        print(f"{(s - t0) / 1e3:9.1f} {gap:7.1f} {(e - s) / 1e3:8.1f} {q:>6}  {wgs:6d}  {short}")
         busy += max(0, e - max(s, end_prev))
         end_prev = max(end_prev, e)
         per[short][0] += 1
