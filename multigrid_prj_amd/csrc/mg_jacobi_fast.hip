@@ -817,13 +817,15 @@ bool rb_fused_ok(const Geom &g)
 
 // coarse != nullptr: the sweep reads u + P coarse (prolong-add folded in, like launch_jacobi2_corr)
 // zero_u: u is identically zero and is not read (the first pre-smoothing sweep of a coarse level: its memset is skipped)
+// d_partials (wide tiles only): the sweep also leaves sum (rhs - A u)^2 of its INPUT as one partial sum per workgroup; returns
+// how many were written (0: this launch did not compute them)
 template <typename T>
-void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs, T *out,
-                     const T *coarse, const Geom &gc, int dup, bool zero_u)
+int launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs, T *out,
+                    const T *coarse, const Geom &gc, int dup, bool zero_u, double *d_partials)
 {
     constexpr int V = VecOf<T>::V;
     if (coarse) { dup = 0; zero_u = false; }   // the folding variant only runs on whole levels
-    if (pair_wide_ok<T>(g)) { launch_pair_wide<T>(s, g, gc, c, (T)1, u, coarse, rhs, out, zero_u, true, dup); return; }
+    if (pair_wide_ok<T>(g)) return launch_pair_wide<T>(s, g, gc, c, (T)1, u, coarse, rhs, out, zero_u, true, dup, d_partials);
     const int tpr = (g.nx - 1) / V;
     const int ncopy = (dup > 0 && !coarse) ? 2 : 1;
     static const int tyo_env = [] { const char *e = getenv("MG_J2_TYO"); return e ? atoi(e) : 3; }();
@@ -848,12 +850,13 @@ void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u,
     default: MG_RB2(64); break;
     }
 #undef MG_RB2
+    return 0;
 }
 
 template bool rb_fused_ok<double>(const Geom &);
 template bool rb_fused_ok<float>(const Geom &);
-template void launch_rb_fused<double>(hipStream_t, const Geom &, const Coef<double> &, const double *, const double *, double *, const double *, const Geom &, int, bool);
-template void launch_rb_fused<float>(hipStream_t, const Geom &, const Coef<float> &, const float *, const float *, float *, const float *, const Geom &, int, bool);
+template int launch_rb_fused<double>(hipStream_t, const Geom &, const Coef<double> &, const double *, const double *, double *, const double *, const Geom &, int, bool, double *);
+template int launch_rb_fused<float>(hipStream_t, const Geom &, const Coef<float> &, const float *, const float *, float *, const float *, const Geom &, int, bool, double *);
 
 // prolong-add + two Jacobi sweeps in one pass: out = J(J(u + P coarse))
 template <typename T>

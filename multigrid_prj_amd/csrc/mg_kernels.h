@@ -65,8 +65,8 @@ template <typename T> void zebra_line_factors(T cl, T cd, int n, T *out);
 // one whole red-black sweep in one pass (same gate as the fused double Jacobi sweep)
 template <typename T> bool rb_fused_ok(const Geom &g);
 template <typename T>
-void launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs, T *out,
-                     const T *coarse, const Geom &gc, int dup_planes = 0, bool zero_u = false);
+int launch_rb_fused(hipStream_t s, const Geom &g, const Coef<T> &c, const T *u, const T *rhs, T *out,
+                    const T *coarse, const Geom &gc, int dup_planes = 0, bool zero_u = false, double *d_partials = nullptr);
 // out-of-place colour half-sweep (the other colour is copied): red u->tmp, black tmp->u
 template <typename T>
 void launch_rb_fast(hipStream_t s, const Geom &g, const Coef<T> &c, int colour, const T *u, const T *rhs, T *out);

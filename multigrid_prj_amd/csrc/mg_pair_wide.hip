@@ -560,10 +560,12 @@ int launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T>
     hipLaunchKernelGGL((k_pairw<T, TPR, GG, D, C, Z, RBB>), dim3(grid), dim3(TPR * GG), 0, s, g, c, omega, u, rhs, out, nby, zc, coarse, gc, dup, (double *)nullptr)
 #define MG_PWN(TPR, GG, D) \
     hipLaunchKernelGGL((k_pairw<T, TPR, GG, D, false, false, false, true>), dim3(grid), dim3(TPR * GG), 0, s, g, c, omega, u, rhs, out, nby, zc, coarse, gc, dup, d_partials)
-    const bool norm = d_partials && !rb && !coarse && !zero_u;
+#define MG_PWNRB(TPR, GG) \
+    hipLaunchKernelGGL((k_pairw<T, TPR, GG, false, false, false, true, true>), dim3(grid), dim3(TPR * GG), 0, s, g, c, omega, u, rhs, out, nby, zc, coarse, gc, dup, d_partials)
+    const bool norm = d_partials && !coarse && !zero_u;
 #define MG_PW_SHAPE(TPR, GG) \
     do { \
-        if (norm) { if (damped) MG_PWN(TPR, GG, true); else MG_PWN(TPR, GG, false); } \
+        if (norm) { if (rb) MG_PWNRB(TPR, GG); else if (damped) MG_PWN(TPR, GG, true); else MG_PWN(TPR, GG, false); } \
         else if (rb) { if (coarse) MG_PW(TPR, GG, false, true, false, true); else if (zero_u) MG_PW(TPR, GG, false, false, true, true); else MG_PW(TPR, GG, false, false, false, true); } \
         else if (coarse) { if (damped) MG_PW(TPR, GG, true, true, false, false); else MG_PW(TPR, GG, false, true, false, false); } \
         else if (zero_u) { if (damped) MG_PW(TPR, GG, true, false, true, false); else MG_PW(TPR, GG, false, false, true, false); } \
@@ -575,6 +577,7 @@ int launch_pair_wide(hipStream_t s, const Geom &g, const Geom &gc, const Coef<T>
 #undef MG_PW_SHAPE
 #undef MG_PW
 #undef MG_PWN
+#undef MG_PWNRB
     return norm ? grid : 0;   // partial sums written (one per workgroup launched)
 }
 

@@ -1037,9 +1037,15 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
             }
             if (!L.dist && rb_fused_ok<T>(L.g)) {  // both colours in one pass over HBM; the sweep lands in TMP
                 const bool corr = (s == 0 && corr_level >= 0);
-                launch_rb_fused<T>(stream_, L.g, c, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
-                                   corr ? ptr<T>(ax, corr_level) : (const T *)nullptr, lv_[corr ? corr_level : level].g, 0,
-                                   x_zero && s == 0);
+                // (Solver::solve: the first pre-smoothing sweep of level 0 also sums (rhs - A u)^2 of its input)
+                const bool norm = want_pair_norm_ && level == 0 && s == 0 && !corr && !x_zero && ax == MG_ARR_U && ar == MG_ARR_RHS;
+                const int np = launch_rb_fused<T>(stream_, L.g, c, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level),
+                                                  corr ? ptr<T>(ax, corr_level) : (const T *)nullptr, lv_[corr ? corr_level : level].g, 0,
+                                                  x_zero && s == 0, norm ? d_partials_ : (double *)nullptr);
+                if (norm && np > 0) {
+                    launch_reduce_final(stream_, d_partials_, np, d_scal_);
+                    pair_norm_done_ = true;
+                }
                 std::swap(L.base[ax], L.base[MG_ARR_TMP]);
                 launches++;
                 continue;
@@ -1374,8 +1380,11 @@ int Solver::vcycle_rec_t(int l, bool u_zero)
         if (!skip0) MG_TRY(zero_array(MG_ARR_U, l + 1));
         MG_TRY(vcycle_rec_t<T>(l + 1, skip0));
     } else if (mine) {
-        if (l == 0 && fine_pre_done_) fine_pre_done_ = false;   // Solver::solve ran this level's pre-smoothing with the norm
-        else MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero, -1, true));
+        if (l == 0 && fine_pre_done_ > 0) {   // Solver::solve ran (the first sweeps of) this level's pre-smoothing with the norm
+            const int left = d_.nu_pre - fine_pre_done_;
+            fine_pre_done_ = 0;
+            if (left > 0) MG_TRY(smooth_t<T>(l, d_.smoother, left, MG_ARR_U, MG_ARR_RHS, false, -1, true));
+        } else MG_TRY(smooth_t<T>(l, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, u_zero, -1, true));
         if (prof) MG_TRY(prof_begin(l));
         if (!fuse_rr && !fuse_rr_slab) MG_TRY(residual_t<T>(l, MG_ARR_U, MG_ARR_RHS, MG_ARR_TMP, false));
     }
@@ -1527,9 +1536,10 @@ bool Solver::pair_norm_ok() const
 {
     static const bool enabled = [] { const char *e = getenv("MG_PAIR_NORM"); return !(e && e[0] == '0'); }();
     const Level &L = lv_[0];
-    return enabled && d_.cycle == MG_CYCLE_V && d_.levels > 1 && d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre == 2 &&
-           d_.outer_pre_gs == 0 && !stage_fn_ && !profiling_ && L.present && !L.dist && nranks_ == 1 &&
-           jacobi2_ok<T>(L.g) && pair_wide_ok<T>(L.g);
+    const bool sm = (d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre == 2 && jacobi2_ok<T>(L.g)) ||
+                    (d_.smoother == MG_SMOOTH_RBGS && d_.nu_pre >= 1 && rb_fused_ok<T>(L.g));   // red-black: the first sweep carries it
+    return enabled && d_.cycle == MG_CYCLE_V && d_.levels > 1 && sm &&
+           d_.outer_pre_gs == 0 && !stage_fn_ && !profiling_ && L.present && !L.dist && nranks_ == 1 && pair_wide_ok<T>(L.g);
 }
 
 // Outer loop of src/main.cpp:72-116.
@@ -1549,8 +1559,11 @@ int Solver::solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist
         for (int it = 0; it <= maxit; it++) {
             void *const base_u = L0.base[MG_ARR_U], *const base_t = L0.base[MG_ARR_TMP];
             want_pair_norm_ = true; pair_norm_done_ = false;
-            const int rc = d_.dtype == MG_F64 ? smooth_t<double>(0, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, false, -1, true)
-                                              : smooth_t<float>(0, d_.smoother, d_.nu_pre, MG_ARR_U, MG_ARR_RHS, false, -1, true);
+            // the speculative launch: the Jacobi pair (both pre-smoothing sweeps), or the first red-black sweep -- ONE out-of-place
+            // launch either way, so the iterate the norm belongs to is still whole when the test says stop
+            const int spec = d_.smoother == MG_SMOOTH_JACOBI ? d_.nu_pre : 1;
+            const int rc = d_.dtype == MG_F64 ? smooth_t<double>(0, d_.smoother, spec, MG_ARR_U, MG_ARR_RHS, false, -1, true)
+                                              : smooth_t<float>(0, d_.smoother, spec, MG_ARR_U, MG_ARR_RHS, false, -1, true);
             want_pair_norm_ = false;
             MG_TRY(rc);
             if (!pair_norm_done_) { set_last_error("mg_solve: the pre-smoothing pair did not deliver the residual norm"); return MG_ERR_HIP; }
@@ -1571,9 +1584,9 @@ int Solver::solve(double tol, int maxit, double *hist, int hist_cap, int *n_hist
                 L0.base[MG_ARR_U] = base_u; L0.base[MG_ARR_TMP] = base_t;
                 break;
             }
-            fine_pre_done_ = true;
+            fine_pre_done_ = spec;
             const int crc = cycle_enqueue();
-            fine_pre_done_ = false;
+            fine_pre_done_ = 0;
             MG_TRY(crc);
             if (per_cycle) MG_HIP(hipMemcpyAsync(h_coarse_, d_coarse_, sizeof(CoarseOut), hipMemcpyDeviceToHost, stream_));
         }

@@ -172,9 +172,10 @@ private:
     int post(const P2POp *ops, int n, hipStream_t s);  // comm_->batch + the counters
     int lock_iters_ = -1;  // >= 0: the next coarse solve runs exactly this many sweeps (lock-step parity mode)
     // Outer loop with the residual norm taken inside the next cycle's first pre-smoothing pair (Solver::solve): want_pair_norm_
-    // asks smooth_t for it, pair_norm_done_ says the pair delivered it into d_scal_[0], fine_pre_done_ tells vcycle_rec_t that
-    // level 0's pre-smoothing has already run.
-    bool want_pair_norm_ = false, pair_norm_done_ = false, fine_pre_done_ = false;
+    // asks smooth_t for it, pair_norm_done_ says the launch delivered it into d_scal_[0], fine_pre_done_ tells vcycle_rec_t how
+    // many of level 0's pre-smoothing sweeps have already run (Jacobi: the pair = 2; red-black: the first sweep = 1).
+    bool want_pair_norm_ = false, pair_norm_done_ = false;
+    int fine_pre_done_ = 0;
     template <typename T> bool pair_norm_ok() const;
     Geom gfull_{};
     void *full_[3] = {nullptr, nullptr, nullptr};

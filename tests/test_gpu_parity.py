@@ -266,15 +266,18 @@ def test_vcycle_headline_size_513_bit_exact(smoother):
         assert np.array_equal(sg.get_solution(), so.get_solution())
 
 
-@pytest.mark.parametrize("n,dtype,levels", [(257, capi.MG_F64, 5), (513, capi.MG_F32, 6)])
-def test_solve_takes_the_residual_norm_inside_the_next_pre_smoothing_pair(n, dtype, levels):
+@pytest.mark.parametrize("n,dtype,levels,smoother", [(257, capi.MG_F64, 5, capi.SMOOTH_JACOBI), (513, capi.MG_F32, 6, capi.SMOOTH_JACOBI),
+                                                    (257, capi.MG_F64, 5, capi.SMOOTH_RBGS), (513, capi.MG_F32, 6, capi.SMOOTH_RBGS)],
+                         ids=["257-f64-jacobi", "513-f32-jacobi", "257-f64-redblack", "513-f32-redblack"])
+def test_solve_takes_the_residual_norm_inside_the_next_pre_smoothing_pair(n, dtype, levels, smoother):
     """mg_solve on a level wide enough for the wide-tile pair (mg_pair_wide.hip: NORM) computes each history entry inside the
     first pre-smoothing pair of the NEXT cycle and drops the speculative pair when the loop stops (src/main.cpp:86-89). The
     outer loop done by hand -- mg_cycle + mg_residual per iteration, the separate norm kernel -- must give the same history
     (summation order differs: rtol), the same number of entries when the tolerance stops the loop, and the same iterate BIT
-    FOR BIT; a cycle after the solve must continue from that iterate."""
+    FOR BIT; a cycle after the solve must continue from that iterate. Red-black: the FIRST pre-smoothing sweep carries the
+    norm (one out-of-place launch, dropped on stop) and the cycle runs the second."""
     kw = dict(dim=3, n=n, levels=levels, dtype=dtype, length=1.0, alpha=1.0, cycle=capi.CYCLE_V, nu_pre=2, nu_post=2,
-              smoother=capi.SMOOTH_JACOBI, omega=6 / 7, restriction=capi.RESTRICT_FULLW,
+              smoother=smoother, omega=6 / 7 if smoother == capi.SMOOTH_JACOBI else 1.0, restriction=capi.RESTRICT_FULLW,
               coarse_mode=capi.COARSE_FIXED, coarse_maxit=20, outer_pre_gs=0)
     b = po.fill_rhs_3d(n, 1.0, 1.0, 1)
     if dtype == capi.MG_F32:
