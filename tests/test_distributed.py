@@ -341,18 +341,20 @@ def test_hip_distributed_public_smooth_leaves_e_alone(rb, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,levels,dtype,rb", [(2, 257, 5, 0, False), (3, 257, 5, 0, False), (2, 129, 4, 1, False), (2, 257, 5, 0, True)])
-def test_rccl_transport_carries_the_distributed_cycle(world, n, levels, dtype, rb, tmp_path):
+@pytest.mark.parametrize("world,n,levels,dtype,rb,policy", [(2, 257, 5, 0, False, "0"), (3, 257, 5, 0, False, "0"), (2, 129, 4, 1, False, "0"),
+                                                            (2, 257, 5, 0, True, "0"), (3, 257, 5, 0, False, "32"), (2, 257, 5, 1, True, "32")])
+def test_rccl_transport_carries_the_distributed_cycle(world, n, levels, dtype, rb, policy, tmp_path):
     """The PRODUCT transport with real peers: `world` ranks, one RCCL communicator, grouped ncclSend/ncclRecv on the solver's
     main and communication streams (overlapped interior / boundary pieces, early exchange, halo reuse, prolongation fold on
     slabs), the all-gather of the coarse right-hand side and ncclAllReduce of the norms -- all ranks on the box's one GPU, each
     claiming a host of its own so that RCCL accepts them (socket transport on loopback; see tests/dist_worker.py). The result
-    must be the single-GPU solver's and the oracle's, bit for bit, and the histories must agree on every rank."""
+    must be the single-GPU solver's and the oracle's, bit for bit, and the histories must agree on every rank. policy "32" =
+    the library's default MG_OVERLAP_MIN_MB: these small slabs then exchange on the main stream and run one launch per operation."""
     from multigrid_prj_amd import capi
     case, desc, b = _case(tmp_path, n, levels, 1, cycles=3, dtype=dtype, rb=rb)
     desc["dist_min_n"] = 65
     case["desc"] = desc
-    u, hists, fg = _run_ranks("rccl", world, case, tmp_path, timeout=900)
+    u, hists, fg = _run_ranks("rccl", world, case, tmp_path, timeout=900, extra_env={"MG_OVERLAP_MIN_MB": policy})
     assert fg >= 2
     with capi.Solver(capi.make_desc(**desc)) as s:
         s.set_rhs(b)
