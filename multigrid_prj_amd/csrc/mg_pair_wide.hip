@@ -359,14 +359,13 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
     fetch(z0, z0 - 1);
 
     for (int p = z0 - 1; p <= z1; p++) {
-        // ---- this step's operands were requested one step ago; the next step's are requested now
+        // ---- this step's operands were requested one step ago (between the two sweeps of the last step)
         vec b[R], hn = nh;
         T vtail[R], ter_n[R], hter_n = nhter;
 #pragma unroll
         for (int r = 0; r < R; r++) { up[r] = nu[r]; b[r] = nb[r]; ter_n[r] = nter[r]; vtail[r] = nvt[r]; }
         T Ra[3][NR], Rb[3][NR];
         if (CORR) raw(p + 1, Ra, Rb);
-        else if (!NORM) fetch(p + 2, p + 1);
         // ---- u(p+1) + P e -> LDS slot (p+1)&1 (read by the next step's first sweep)
         if (CORR) {
             T Z[3][NR];
@@ -421,9 +420,11 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
                 *(vec *)&sv[sc][i0 + r][V + x0] = v[r];
             }
         }
-        // (the residual's / the correction's extra live values would not fit beside the next operands any earlier; for the folding
-        // variant this placement also measured 2.5-3 % faster than right after the correction)
-        if (NORM || CORR) fetch(p + 2, p + 1);
+        // ---- the next step's operands are requested HERE, between the two sweeps: every variant measured faster with them here than
+        // at the top of the step (same-box A/B of tools/pairbench at 513^3 fp64: plain pair 0.670 -> 0.641 ms, folding pair
+        // 0.753 -> 0.736, red-black sweep 0.650 -> 0.630, 64-plane slab piece 0.095 -> 0.089) -- the first sweep's arithmetic
+        // runs with the registers of the prefetch still free, and the requests overlap the second sweep and the barrier
+        fetch(p + 2, p + 1);
         // ---- second sweep on plane q = p-1, output rows
         const int q = p - 1;
         if (q >= z0 && q < z1) {

@@ -990,11 +990,10 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
                     launch_jacobi2_corr<T>(stream_, L.g, lv_[corr_level].g, c, (T)d_.omega, ptr<T>(ax, level),
                                            ptr<T>(ax, corr_level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level));
                 else {  // x_zero: the pair starts from an implicit zero guess (nothing is read for x)
-                    // The variant of the wide-tile pair that also sums (rhs - A u)^2 runs 4 % FASTER inside the cycle than the one
-                    // without (0.63 against 0.66 ms at 513^3, three alternating bench runs on one box; its next-plane requests sit
-                    // between its two sweeps, but moving them there in the plain variant made that one slower -- not understood):
-                    // level 0's pre-smoothing pair always takes it, the partial sums are only reduced when the outer loop asks.
-                    static const bool always_norm = [] { const char *e = getenv("MG_ALWAYS_NORM"); return !(e && e[0] == '0'); }();
+                    // The variant of the wide-tile pair that also sums (rhs - A u)^2 costs 1.5 % over the plain one (0.636 against 0.626 ms
+                    // at 513^3, alternating bench runs on one box): level 0's pre-smoothing pair takes it when the outer loop asks
+                    // for the norm (MG_ALWAYS_NORM=1: always, as in the first half of round 3 when it was the faster of the two).
+                    static const bool always_norm = [] { const char *e = getenv("MG_ALWAYS_NORM"); return e && e[0] == '1'; }();
                     const bool norm = (want_pair_norm_ || always_norm) && level == 0 && s == 0 && !x_zero && ax == MG_ARR_U && ar == MG_ARR_RHS;
                     const int np = launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level),
                                                      ptr<T>(MG_ARR_TMP, level), x_zero && s == 0, 0, norm ? d_partials_ : (double *)nullptr);
