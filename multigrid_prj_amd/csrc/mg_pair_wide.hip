@@ -336,26 +336,31 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
     // (all 16 waves of the tile meet at one barrier per plane: without it the CU alternates between waiting and computing).
     vec nu[R], nb[R], nh = (vec)(0);
     T nter[R], nvt[R], nhter = 0;
-    auto fetch = [&](int pu1, int pb) {   // raw u of plane pu1 (rows, halo row, tail column) and rhs of plane pb
-        const long long pn = plane_of(pu1), po = plane_of(pb);
+    auto fetch_u = [&](int pu1) {
+        const long long pn = plane_of(pu1);
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            nu[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (pn + urow[r])) + x0);
-            nb[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
-        }
+        for (int r = 0; r < R; r++) nu[r] = ZEROU ? (vec)(0) : *(const vec *)((u + (pn + urow[r])) + x0);
         if (!ZEROU && (lo_grp || hi_grp)) nh = *(const vec *)((u + (pn + hrow)) + x0);
-        // the Dirichlet column nx-1 (the row's last thread): ONE predicated region for all its values
 #pragma unroll
-        for (int r = 0; r < R; r++) { nter[r] = 0; nvt[r] = 0; }
+        for (int r = 0; r < R; r++) nter[r] = 0;
         if (tail) {
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                if (!ZEROU) nter[r] = (u + (pn + urow[r]))[x0 + V];
-                nvt[r] = (rhs + (po + urow[r]))[x0 + V];  // first sweep on the Dirichlet column: v = rhs
-            }
+            for (int r = 0; r < R; r++) if (!ZEROU) nter[r] = (u + (pn + urow[r]))[x0 + V];
             if (!ZEROU && (lo_grp || hi_grp)) nhter = (u + (pn + hrow))[x0 + V];
         }
     };
+    auto fetch_b = [&](int pb) {
+        const long long po = plane_of(pb);
+#pragma unroll
+        for (int r = 0; r < R; r++) nb[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
+#pragma unroll
+        for (int r = 0; r < R; r++) nvt[r] = 0;
+        if (tail) {
+#pragma unroll
+            for (int r = 0; r < R; r++) nvt[r] = (rhs + (po + urow[r]))[x0 + V];
+        }
+    };
+    auto fetch = [&](int pu1, int pb) { fetch_u(pu1); fetch_b(pb); };
     fetch(z0, z0 - 1);
 
     for (int p = z0 - 1; p <= z1; p++) {
@@ -424,7 +429,11 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
         // at the top of the step (same-box A/B of tools/pairbench at 513^3 fp64: plain pair 0.670 -> 0.641 ms, folding pair
         // 0.753 -> 0.736, red-black sweep 0.650 -> 0.630, 64-plane slab piece 0.095 -> 0.089) -- the first sweep's arithmetic
         // runs with the registers of the prefetch still free, and the requests overlap the second sweep and the barrier
-        fetch(p + 2, p + 1);
+        // (the right-hand side's rows a little later still, after the second sweep, where no coarse rows are in flight and u is read at
+        // all: plain pair and red-black sweep -2 %; the folding variant +5 % and the zero-guess pair +17 % with them there)
+        constexpr bool LATE_B = !CORR && !ZEROU;
+        fetch_u(p + 2);
+        if (!LATE_B) fetch_b(p + 1);
         // ---- second sweep on plane q = p-1, output rows
         const int q = p - 1;
         if (q >= z0 && q < z1) {
@@ -462,6 +471,7 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
                 }
             }
         }
+        if (LATE_B) fetch_b(p + 1);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; r++) { um[r] = uc[r]; uc[r] = up[r]; vm[r] = vc[r]; vc[r] = v[r]; bq[r] = b[r]; }
