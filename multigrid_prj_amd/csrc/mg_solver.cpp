@@ -834,7 +834,7 @@ template <typename T>
 // u_halo_ok: U's two ghost planes either side already hold the neighbours' current planes (the residual + restriction of this
 // cycle fetched them and nothing has written U since -- true for the folding pair, which reads the uncorrected u): no exchange,
 // and with nothing to hide behind an interior launch the whole slab is ONE launch.
-int Solver::pair_on_slab2_t(int level, bool rb, int corr_level, bool u_halo_ok)
+int Solver::pair_on_slab2_t(int level, bool rb, int corr_level, bool u_halo_ok, double *norm_partials, int *norm_np)
 {
     Level &L = lv_[level];
     const Geom &g = L.g;
@@ -856,7 +856,14 @@ int Solver::pair_on_slab2_t(int level, bool rb, int corr_level, bool u_halo_ok)
     static const bool one_boundary_launch = [] { const char *e = getenv("MG_MERGE_BOUNDARY"); return !(e && e[0] == '0'); }();
     MG_TRY(refresh_rhs_halo(level));
     static const bool reuse_halo = [] { const char *e = getenv("MG_REUSE_HALO"); return !(e && e[0] == '0'); }();
-    if (u_halo_ok && reuse_halo) {
+    if (norm_partials && !rb && !pe) {
+        // Solver::solve's speculative pair: the whole slab in ONE wide-tile launch that also sums (rhs - A u)^2 of its input over
+        // the owned planes (no interior / boundary split: the thin boundary pieces have no norm variant; the separate residual
+        // norm this replaces needed the same exchange and a pass over the slab of its own)
+        MG_TRY(exchange(MG_ARR_U, level, 2));
+        const int np = launch_jacobi2<T>(stream_, g, c, om, px, pr, pt, false, 0, norm_partials);
+        if (norm_np) *norm_np = np;
+    } else if (u_halo_ok && reuse_halo) {
         fused(g, 0);
     } else if (!L.overlap || g.nz < 8) {
         MG_TRY(exchange(MG_ARR_U, level, 2));
@@ -973,7 +980,14 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
                     launch_jacobi2<T>(stream_, L.g, c, (T)d_.omega, ptr<T>(ax, level), ptr<T>(ar, level), ptr<T>(MG_ARR_TMP, level), true);
                     std::swap(L.base[ax], L.base[MG_ARR_TMP]);
                 } else {
-                    MG_TRY(pair_on_slab2_t<T>(level, false, s == 0 ? corr_level : -1, s == 0 && u_halo_ok));
+                    const bool norm = want_pair_norm_ && level == 0 && s == 0 && corr_level < 0;
+                    int np = 0;
+                    MG_TRY(pair_on_slab2_t<T>(level, false, s == 0 ? corr_level : -1, s == 0 && u_halo_ok, norm ? d_partials_ : (double *)nullptr, &np));
+                    if (norm && np > 0) {   // sum r^2 of the pair's input over this rank's planes, then over the ranks -> d_scal_[0]
+                        launch_reduce_final(stream_, d_partials_, np, d_scal_);
+                        MG_TRY(allreduce(d_scal_, 1));
+                        pair_norm_done_ = true;
+                    }
                 }
                 s++; launches += 1;   // counted as ONE segment: exchange + interior + boundary launches
                 continue;
@@ -1535,10 +1549,15 @@ bool Solver::pair_norm_ok() const
 {
     static const bool enabled = [] { const char *e = getenv("MG_PAIR_NORM"); return !(e && e[0] == '0'); }();
     const Level &L = lv_[0];
+    if (!enabled || d_.cycle != MG_CYCLE_V || d_.levels <= 1 || d_.outer_pre_gs != 0 || stage_fn_ || profiling_ || !L.present) return false;
+    if (L.dist) {   // z-slabs: the Jacobi pair on the whole slab (two ghost planes), wide enough on the thinnest slab of all ranks
+        static const bool slab_enabled = [] { const char *e = getenv("MG_PAIR_NORM_SLAB"); return !(e && e[0] == '0'); }();
+        const Geom gs = slab_gate_geom(L);
+        return slab_enabled && d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre == 2 && depth2_enabled() && jacobi2_slab_ok<T>(gs) && pair_wide_ok<T>(gs);
+    }
     const bool sm = (d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre == 2 && jacobi2_ok<T>(L.g)) ||
                     (d_.smoother == MG_SMOOTH_RBGS && d_.nu_pre >= 1 && rb_fused_ok<T>(L.g));   // red-black: the first sweep carries it
-    return enabled && d_.cycle == MG_CYCLE_V && d_.levels > 1 && sm &&
-           d_.outer_pre_gs == 0 && !stage_fn_ && !profiling_ && L.present && !L.dist && nranks_ == 1 && pair_wide_ok<T>(L.g);
+    return sm && nranks_ == 1 && pair_wide_ok<T>(L.g);
 }
 
 // Outer loop of src/main.cpp:72-116.

@@ -104,7 +104,7 @@ private:
     template <typename T> bool can_fold_prolong_slab(int level) const;   // both levels distributed: the slab pair folds P e in
     template <typename T> bool can_fold_prolong_replicated(int level) const;   // slab level over a level every rank holds whole
     template <typename T> int pair_on_slab_t(int level, bool rb);
-    template <typename T> int pair_on_slab2_t(int level, bool rb, int corr_level = -1, bool u_halo_ok = false);   // depth-2 ghosts: one exchange, the fused kernel on the whole slab
+    template <typename T> int pair_on_slab2_t(int level, bool rb, int corr_level = -1, bool u_halo_ok = false, double *norm_partials = nullptr, int *norm_np = nullptr);   // depth-2 ghosts: one exchange, the fused kernel on the whole slab
     template <typename T> int resid_restrict_on_slab_t(int level, const Geom &gc, T *coarse_rhs);
     int refresh_rhs_halo(int level);
     template <typename T> bool can_skip_zeroing(int level) const;
