@@ -856,12 +856,13 @@ int Solver::pair_on_slab2_t(int level, bool rb, int corr_level, bool u_halo_ok, 
     static const bool one_boundary_launch = [] { const char *e = getenv("MG_MERGE_BOUNDARY"); return !(e && e[0] == '0'); }();
     MG_TRY(refresh_rhs_halo(level));
     static const bool reuse_halo = [] { const char *e = getenv("MG_REUSE_HALO"); return !(e && e[0] == '0'); }();
-    if (norm_partials && !rb && !pe) {
+    if (norm_partials && !pe) {
         // Solver::solve's speculative pair: the whole slab in ONE wide-tile launch that also sums (rhs - A u)^2 of its input over
         // the owned planes (no interior / boundary split: the thin boundary pieces have no norm variant; the separate residual
         // norm this replaces needed the same exchange and a pass over the slab of its own)
         MG_TRY(exchange(MG_ARR_U, level, 2));
-        const int np = launch_jacobi2<T>(stream_, g, c, om, px, pr, pt, false, 0, norm_partials);
+        const int np = rb ? launch_rb_fused<T>(stream_, g, c, px, pr, pt, (const T *)nullptr, g, 0, false, norm_partials)
+                          : launch_jacobi2<T>(stream_, g, c, om, px, pr, pt, false, 0, norm_partials);
         if (norm_np) *norm_np = np;
     } else if (u_halo_ok && reuse_halo) {
         fused(g, 0);
@@ -1038,7 +1039,14 @@ int Solver::smooth_t(int level, int smoother, int sweeps, int ax, int ar, bool x
         for (int s = 0; s < sweeps; s++) {
             pair_on_comm_level_ = -1;
             if (L.dist && depth2_enabled() && ax == MG_ARR_U && ar == MG_ARR_RHS && jacobi2_slab_ok<T>(slab_gate_geom(L)) && rb_slab_enabled()) {
-                MG_TRY(pair_on_slab2_t<T>(level, true));   // one-pass red-black sweep on the whole slab, two ghost planes
+                const bool norm = want_pair_norm_ && level == 0 && s == 0 && corr_level < 0;
+                int np = 0;
+                MG_TRY(pair_on_slab2_t<T>(level, true, -1, false, norm ? d_partials_ : (double *)nullptr, &np));   // one-pass red-black sweep on the whole slab, two ghost planes
+                if (norm && np > 0) {
+                    launch_reduce_final(stream_, d_partials_, np, d_scal_);
+                    MG_TRY(allreduce(d_scal_, 1));
+                    pair_norm_done_ = true;
+                }
                 launches += 1;
                 continue;
             }
@@ -1553,7 +1561,8 @@ bool Solver::pair_norm_ok() const
     if (L.dist) {   // z-slabs: the Jacobi pair on the whole slab (two ghost planes), wide enough on the thinnest slab of all ranks
         static const bool slab_enabled = [] { const char *e = getenv("MG_PAIR_NORM_SLAB"); return !(e && e[0] == '0'); }();
         const Geom gs = slab_gate_geom(L);
-        return slab_enabled && d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre == 2 && depth2_enabled() && jacobi2_slab_ok<T>(gs) && pair_wide_ok<T>(gs);
+        const bool sm = (d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre == 2) || (d_.smoother == MG_SMOOTH_RBGS && d_.nu_pre >= 1 && rb_slab_enabled());
+        return slab_enabled && sm && depth2_enabled() && jacobi2_slab_ok<T>(gs) && pair_wide_ok<T>(gs);
     }
     const bool sm = (d_.smoother == MG_SMOOTH_JACOBI && d_.nu_pre == 2 && jacobi2_ok<T>(L.g)) ||
                     (d_.smoother == MG_SMOOTH_RBGS && d_.nu_pre >= 1 && rb_fused_ok<T>(L.g));   // red-black: the first sweep carries it
