@@ -20,6 +20,7 @@
 #include "mg_kernels.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdlib>
 
@@ -109,10 +110,14 @@ __global__ __launch_bounds__(TPR * G) void k_rrw(Geom gf, Geom gc, Coef<T> c, co
     auto bplane = [&](int p) { return (long long)min(p, ze) * gf.plane; };
 
     vec um[R], uc[R], up[R];
-    // the next step's operands are requested one step ahead (two steps ahead was measured slower: 0.60 against 0.55 ms at
-    // 513^3 -- the memory system is saturated by one step's worth in flight per CU): u at the top of the step, rhs after the residual
-    vec nu[R], nb[R], nh = (vec)(0);
-    T nter[R], nbt[R], nhter = 0;
+    // The next step's u rows are requested one step ahead (at the top of the step), the right-hand side's rows TWO steps ahead
+    // (after the residual, into the register set the step has just consumed: the two sets alternate with the step's parity, so
+    // no register is moved while its load is in flight). A build without the arithmetic (loads, LDS publish and barrier only)
+    // takes 0.42 ms at 513^3 -- the read ceiling of the chip -- against 0.527 with it: the arithmetic of a step is not hidden
+    // behind one step's worth of requests; with the rhs rows two deep 0.44-0.49 (64-plane slab piece 0.072 -> 0.063).
+    // (Everything two steps ahead through register moves had measured slower, 0.60 against 0.55 ms.)
+    vec nu[R], nb[2][R], nh = (vec)(0);   // rhs: two register sets, requested TWO steps ahead (the sets alternate with the step's parity)
+    T nter[R], nbt[2][R], nhter = 0;
     auto fetch_u = [&](int pu1) {
         const long long pn = uplane(pu1);
 #pragma unroll
@@ -126,18 +131,18 @@ __global__ __launch_bounds__(TPR * G) void k_rrw(Geom gf, Geom gc, Coef<T> c, co
             if (lo_grp || hi_grp) nhter = (u + (pn + hrow))[x0 + V];
         }
     };
-    auto fetch_b = [&](int pb) {
+    auto fetch_b = [&](int pb, auto PAR) {
+        constexpr int P = decltype(PAR)::value;
         const long long po = bplane(pb);
 #pragma unroll
-        for (int r = 0; r < R; r++) nb[r] = *(const vec *)((rhs + (po + urow[r])) + x0);
+        for (int r = 0; r < R; r++) nb[P][r] = *(const vec *)((rhs + (po + urow[r])) + x0);
 #pragma unroll
-        for (int r = 0; r < R; r++) nbt[r] = 0;
+        for (int r = 0; r < R; r++) nbt[P][r] = 0;
         if (tail) {
 #pragma unroll
-            for (int r = 0; r < R; r++) nbt[r] = (rhs + (po + urow[r]))[x0 + V];
+            for (int r = 0; r < R; r++) nbt[P][r] = (rhs + (po + urow[r]))[x0 + V];
         }
     };
-    auto fetch = [&](int pu1, int pb) { fetch_u(pu1); fetch_b(pb); };
     // ---- prologue: u planes zs-1 (registers) and zs (registers + LDS)
     {
         T ter[R];
@@ -171,19 +176,22 @@ __global__ __launch_bounds__(TPR * G) void k_rrw(Geom gf, Geom gc, Coef<T> c, co
             if (xt == 0) { su[0][hs][V - 1] = 0; su[1][hs][V - 1] = 0; }
         }
     }
-    fetch(zs + 1, zs);
+    fetch_u(zs + 1);
+    fetch_b(zs, std::integral_constant<int, 0>{});
+    fetch_b(zs + 1, std::integral_constant<int, 1>{});
     __syncthreads();
 
     T ywm[CV], ywc[CV], ctr[CV], ctr_tail = 0;
 #pragma unroll
     for (int m = 0; m < CV; m++) { ywm[m] = 0; ywc[m] = 0; ctr[m] = 0; }
 
-    for (int z = zs; z <= ze + 1; z++) {
-        // ---- this step's operands were requested one step ago; the next step's are requested now
+    auto step = [&](int z, auto PAR) {
+        constexpr int P = decltype(PAR)::value;
+        // ---- this step's u rows were requested one step ago, its rhs rows two steps ago
         vec b[R], hn = nh;
         T ter_n[R], bt[R], hter_n = nhter;
 #pragma unroll
-        for (int r = 0; r < R; r++) { up[r] = nu[r]; b[r] = nb[r]; ter_n[r] = nter[r]; bt[r] = nbt[r]; }
+        for (int r = 0; r < R; r++) { up[r] = nu[r]; b[r] = nb[P][r]; ter_n[r] = nter[r]; bt[r] = nbt[P][r]; }
         fetch_u(z + 2);
         // ---- u(z+1) -> LDS slot (z+1)&1
         {
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(TPR * G) void k_rrw(Geom gf, Geom gc, Coef<T> c, co
         }
         // (the right-hand side's rows are requested here, after the residual, not with u at the top of the step: whole level 0.540 ->
         // 0.526 ms, 64-plane slab piece 0.078 -> 0.072 in a same-box A/B; after the weights instead 0.536, u after the publish 0.534)
-        fetch_b(z + 1);
+        fetch_b(z + 2, PAR);
         // ---- weights of plane zw = z-1 (its residual rows were published before the last barrier)
         const int zw = z - 1;
         if (zw >= zs && emit_row) {
@@ -285,6 +293,10 @@ __global__ __launch_bounds__(TPR * G) void k_rrw(Geom gf, Geom gc, Coef<T> c, co
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; r++) { um[r] = uc[r]; uc[r] = up[r]; }
+    };
+    for (int z = zs; z <= ze + 1; z += 2) {
+        step(z, std::integral_constant<int, 0>{});
+        if (z + 1 <= ze + 1) step(z + 1, std::integral_constant<int, 1>{});
     }
     }   // next chunk of this workgroup's range
 }
