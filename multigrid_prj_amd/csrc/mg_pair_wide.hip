@@ -331,9 +331,10 @@ __global__ __launch_bounds__(TPR * G) void k_pairw(Geom g, Coef<T> c, T omega, c
 #pragma unroll
     for (int r = 0; r < R; r++) { vm[r] = (vec)(0); vc[r] = (vec)(0); bq[r] = (vec)(0); }
 
-    // Software prefetch, one plane step ahead: the u rows of plane p+2 and the rhs rows of plane p+1 are requested at the top
-    // of step p and consumed at the top of step p+1, so a step's HBM latency runs under the arithmetic of the step before
-    // (all 16 waves of the tile meet at one barrier per plane: without it the CU alternates between waiting and computing).
+    // Software prefetch, one plane step ahead: the u rows of plane p+2 and the rhs rows of plane p+1 are requested in the
+    // middle of step p (see there) and consumed at the top of step p+1, so a step's HBM latency runs under the arithmetic
+    // around it (all 16 waves of the tile meet at one barrier per plane: without it the CU alternates between waiting and
+    // computing). Two steps ahead for the rhs rows, which pays in k_rrw, spills 50 registers here.
     vec nu[R], nb[R], nh = (vec)(0);
     T nter[R], nvt[R], nhter = 0;
     auto fetch_u = [&](int pu1) {

@@ -15,7 +15,8 @@
 //   * the residual rows of plane z go to LDS; the NEXT step weights them: x-weights of the thread's two rows and of the odd
 //     row below (the neighbouring group's: its three x-weights are recomputed, not exchanged), then y, then the z pipeline;
 //     one barrier per plane;
-//   * residual on 2G rows for 2G - 2 coarse-row pairs (8 / 6), u and rhs rows requested one plane ahead into registers.
+//   * residual on 2G rows for 2G - 2 coarse-row pairs (8 / 6); u rows requested one plane ahead, rhs rows two planes ahead
+//     (two register sets alternating with the step's parity: the loop body is instantiated once per parity).
 // Geometry conventions (slab pieces, ghost planes, the second single coarse plane `dup_kc` further up) are k_resid_restrict_fw's.
 #include "mg_kernels.h"
 
